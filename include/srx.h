@@ -1,0 +1,237 @@
+/*
+ * srx — C ABI of the MI355X-native BTV-L1 multiframe super-resolution path.
+ *
+ * Every entry point is plain C (pointers, sizes, ints); no C++ or torch types
+ * cross this boundary.  Each declaration cites the reference interface it
+ * replaces (paths relative to the reference tree).  The C++ facade in
+ * include/srx/superres.hpp re-creates the reference's classes on top of it.
+ *
+ * Threading: a handle is a single stream-ordered context bound to one GPU; it
+ * is not thread-safe (neither is the reference object).  Handles on different
+ * GPUs may be driven from different threads.
+ *
+ * Errors: functions return SRX_OK (0) or an SRX_ERR_* code; srx_last_error()
+ * returns the calling thread's last message.
+ */
+#ifndef SRX_H
+#define SRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRX_API __attribute__((visibility("default")))
+
+enum
+{
+    SRX_OK = 0,
+    SRX_ERR_INVALID = 1, /* bad argument or parameter value            */
+    SRX_ERR_STATE = 2,   /* call not valid in the handle's current state */
+    SRX_ERR_DEVICE = 3,  /* a HIP call failed                          */
+    SRX_ERR_SOURCE = 4,  /* the frame source ran dry during warm-up (CV_Assert at lib/src/btv_l1.cpp:479) */
+    SRX_ERR_FLOW = 5     /* the optical-flow plug-in failed             */
+};
+
+/* depth codes are OpenCV's CV_8U / CV_32F */
+enum
+{
+    SRX_8U = 0,
+    SRX_32F = 5
+};
+enum
+{
+    SRX_MEM_HOST = 0,
+    SRX_MEM_DEVICE = 1
+};
+
+/* Image view: the cv::Mat header reduced to what the path reads.  Channels
+ * are interleaved; step is the row pitch in bytes (0 = dense). */
+typedef struct srx_image
+{
+    void* data;
+    int rows, cols, channels, depth;
+    size_t step;
+    int mem; /* SRX_MEM_HOST or SRX_MEM_DEVICE */
+} srx_image;
+
+typedef struct srx_handle srx_handle;
+
+/* videostab::IFrameSource as used by lib/include/super_resolution.hpp:149
+ * (shape visible in samples/quality_test/main.cpp:43-50): next() fills *out
+ * and returns 1, or returns 0 at the end of the stream (the empty Mat). The
+ * image must stay valid until the next call of next(). */
+typedef int (*srx_next_frame_fn)(void* user, srx_image* out);
+typedef void (*srx_reset_fn)(void* user);
+
+/* DenseOpticalFlow::calc(frame0, frame1, flow1) of
+ * lib/include/optical_flow.hpp:44 for user plug-ins: frames are handed over as
+ * the source delivered them; the plug-in fills *flow (rows x cols, 2 channels,
+ * SRX_32F, interleaved dx,dy; host or device) and returns 0 on success. */
+typedef int (*srx_flow_fn)(void* user, const srx_image* frame0, const srx_image* frame1, srx_image* flow);
+
+enum
+{
+    SRX_FLOW_NONE = 0,    /* no flow set: streaming calls fail with SRX_ERR_FLOW */
+    SRX_FLOW_TVL1 = 1,    /* built-in duality-based TV-L1 on the GPU             */
+    SRX_FLOW_CALLBACK = 2 /* user plug-in                                        */
+};
+
+/* ---- object life cycle ------------------------------------------------- */
+
+/* `new BTV_L1` (samples/video/main.cpp:106); defaults of
+ * BTV_L1_Base::BTV_L1_Base and BTV_L1::BTV_L1 (lib/src/btv_l1.cpp:277-295,
+ * 461-464).  device >= 0 selects the GPU; device == -1 creates a dry-run
+ * handle that runs the host-side bookkeeping only (no GPU needed, outputs
+ * carry sizes but data == NULL). */
+SRX_API int srx_create_btvl1(int device, srx_handle** out);
+SRX_API void srx_destroy(srx_handle* h);
+SRX_API const char* srx_last_error(void);
+
+/* ---- parameters: Algorithm::set / getInt / getDouble -------------------- */
+/* names and types as registered at lib/src/super_resolution.cpp:83-93:
+ * scale, iterations, btvKernelSize, blurKernelSize, temporalAreaRadius (int);
+ * tau, lambda, alpha, blurSigma (double).  Extra int names of this library:
+ * outputMemory (SRX_MEM_*; default host), traceEvents (0/1). */
+SRX_API int srx_set_int(srx_handle* h, const char* name, int value);
+SRX_API int srx_set_double(srx_handle* h, const char* name, double value);
+SRX_API int srx_get_int(srx_handle* h, const char* name, int* value);
+SRX_API int srx_get_double(srx_handle* h, const char* name, double* value);
+
+/* set("opticalFlow", Ptr<DenseOpticalFlow>) — lib/src/super_resolution.cpp:93,
+ * samples/quality_test/main.cpp:267 */
+SRX_API int srx_set_flow_builtin(srx_handle* h, int kind);
+SRX_API int srx_set_flow_callback(srx_handle* h, srx_flow_fn fn, void* user);
+/* parameters of the built-in flow (tau, lambda, theta, epsilon: double;
+ * nscales, warps, iterations: int) */
+SRX_API int srx_flow_set_int(srx_handle* h, const char* name, int value);
+SRX_API int srx_flow_set_double(srx_handle* h, const char* name, double value);
+SRX_API int srx_flow_get_int(srx_handle* h, const char* name, int* value);
+SRX_API int srx_flow_get_double(srx_handle* h, const char* name, double* value);
+
+/* ---- streaming API: SuperResolution ------------------------------------- */
+
+/* SuperResolution::setFrameSource, lib/src/super_resolution.cpp:131-135 */
+SRX_API int srx_set_input(srx_handle* h, srx_next_frame_fn next, srx_reset_fn reset, void* user);
+/* SuperResolution::reset, lib/src/super_resolution.cpp:137-141 */
+SRX_API int srx_reset(srx_handle* h);
+/* SuperResolution::nextFrame, lib/src/super_resolution.cpp:143-152 with
+ * BTV_L1::initImpl / processImpl (lib/src/btv_l1.cpp:466-509).  *out
+ * describes a buffer owned by the handle, valid until the next call on the
+ * handle (the reference returns a Mat aliasing its member dst).  End of
+ * stream: returns SRX_OK with out->rows == 0 (the empty Mat). */
+SRX_API int srx_next_frame(srx_handle* h, srx_image* out);
+
+/* Multi-GPU span support.  Restricts which outputs (indices counted from the
+ * first frame the source delivers) are solved and returned; frames outside
+ * the range still enter the ring and the flow stage so that windows at the
+ * span edges see their halo.  first > last disables the restriction. */
+SRX_API int srx_set_output_range(srx_handle* h, int first, int last);
+
+/* ---- batch API: BTV_L1_Base::process ------------------------------------ */
+/* lib/src/btv_l1.cpp:297-326 (motions == NULL: flow frame i -> base is
+ * computed by the flow plug-in) and :328-355 (n-1 consecutive forward
+ * motions).  frames: n images of equal size/type (8U or 32F, 1 or 3
+ * channels).  out: caller buffer (host or device) of
+ * (rows*scale-2B) x (cols*scale-2B), same depth as the frames. */
+SRX_API int srx_process(srx_handle* h, const srx_image* frames, int n, const srx_image* motions, int base_idx,
+                        srx_image* out);
+
+/* DenseOpticalFlow::calc / collectGarbage, lib/include/optical_flow.hpp:44-45.
+ * flow2 == NULL: one interleaved 2-channel result; otherwise planar u and v
+ * (lib/src/optical_flow.cpp:71-81). */
+SRX_API int srx_flow_calc(srx_handle* h, const srx_image* frame0, const srx_image* frame1, srx_image* flow1,
+                          srx_image* flow2);
+SRX_API int srx_collect_garbage(srx_handle* h);
+
+/* Event trace of the streaming driver (needs traceEvents = 1).  Each event is
+ * 5 ints {type, a, b, c, d}: READ{got}, FLOW{i}, SOLVE{idx,start,end,base},
+ * OUT{idx}.  Returns the number of events copied (oldest first) and clears
+ * the log. */
+enum
+{
+    SRX_EV_READ = 1,
+    SRX_EV_FLOW = 2,
+    SRX_EV_SOLVE = 3,
+    SRX_EV_OUT = 4
+};
+SRX_API int srx_drain_events(srx_handle* h, int* buf, int max_events);
+
+/* ---- pure host helpers (no GPU needed) ---------------------------------- */
+
+/* at() of lib/src/ring_buffer.hpp:36-46: borderInterpolate(idx, size, BORDER_WRAP) */
+SRX_API int srx_ring_slot(int index, int size);
+/* window of BTV_L1::processFrame, lib/src/btv_l1.cpp:529-540 */
+SRX_API void srx_window(int idx, int radius, int store_pos, int* start, int* end, int* base);
+/* calcBtvWeights, lib/src/btv_l1.cpp:172-189; w must hold ksize*ksize floats;
+ * returns the number of weights written (22 for ksize 7) */
+SRX_API int srx_calc_btv_weights(int btv_kernel_size, double alpha, float* w);
+/* getGaussianKernel as createGaussianFilter calls it, lib/src/btv_l1.cpp:394 */
+SRX_API int srx_gaussian_kernel(int n, double sigma, float* k);
+/* Contiguous span of output frames owned by `rank` of `world`, and the range
+ * of input frames (halo of `radius` on both sides, clipped) it needs. */
+SRX_API int srx_span_plan(int total_frames, int radius, int world, int rank, int* out_first, int* out_last,
+                          int* in_first, int* in_last);
+
+/* ---- stage-level device entry points ------------------------------------ */
+/* All pointers are device pointers unless the name says host; `stream` is a
+ * hipStream_t (NULL = default stream).  Images are dense, channels interleaved.
+ * These are the kernels the solver is built from; they are exported so that
+ * each stage can be checked in isolation. */
+
+/* calcRelativeMotions, lib/src/btv_l1.cpp:36-57.  fwd_host/rel_host: host
+ * arrays of device pointers (n-1 and n entries), each rows*cols*2 floats. */
+SRX_API int srx_k_relative_motions(const float* const* fwd_host, float* const* rel_host, int n, int base_idx, int rows,
+                                   int cols, void* stream);
+/* upscaleMotions + buildMotionMaps + the float->int16 index conversion of
+ * cv::remap(INTER_NEAREST): lib/src/btv_l1.cpp:59-101,428,441.  rel: LR
+ * relative motion (rows x cols x 2); fwd_map / bwd_map: (rows*scale) x
+ * (cols*scale) x 2 int16 source indices (x, y). */
+SRX_API int srx_k_build_maps(const float* rel, int rows, int cols, int scale, int16_t* fwd_map, int16_t* bwd_map,
+                             void* stream);
+/* cv::resize(INTER_CUBIC) on float images, lib/src/btv_l1.cpp:75,412 */
+SRX_API int srx_k_resize_cubic(const float* src, int srows, int scols, int ch, float* dst, int drows, int dcols,
+                               void* stream);
+/* calcBtvRegularization, lib/src/btv_l1.cpp:191-274 (weights from srx_calc_btv_weights) */
+SRX_API int srx_k_btv_regularization(const float* src, int rows, int cols, int ch, int btv_kernel_size,
+                                     const float* w_host, float* dst, void* stream);
+/* One window frame of the forward chain, lib/src/btv_l1.cpp:428-434:
+ * sign(y - D H M X).  X: hr_rows x hr_cols x ch; bwd_map int16 pairs;
+ * y: (hr_rows/scale) x (hr_cols/scale) x ch; sign_out: one int8x4 per LR
+ * pixel (channels 0..ch-1 in bytes 0..ch-1). */
+SRX_API int srx_k_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const int16_t* bwd_map,
+                               const float* y, int scale, const float* gauss_host, int gauss_n, int8_t* sign_out,
+                               void* stream);
+/* The transposed chain for K frames plus regulariser and update,
+ * lib/src/btv_l1.cpp:437-452: X_out = X + tau * (sum_k M^T H^T D^T sign_k - lambda * btv(X)).
+ * fwd_maps_host / signs_host: host arrays of K device pointers. */
+SRX_API int srx_k_backproject_update(const float* X, float* X_out, int hr_rows, int hr_cols, int ch,
+                                     const int16_t* const* fwd_maps_host, const int8_t* const* signs_host, int K,
+                                     int scale, const float* gauss_host, int gauss_n, int btv_kernel_size,
+                                     const float* w_host, double tau, double lambda, void* stream);
+/* Rect inner(B,B,..) crop of lib/src/btv_l1.cpp:455-456 and, for depth
+ * SRX_8U, Mat::convertTo(CV_8U) (lib/src/btv_l1.cpp:504). */
+SRX_API int srx_k_crop_convert(const float* X, int rows, int cols, int ch, int border, void* dst, int depth,
+                               void* stream);
+
+/* BTV_L1_Base::run, lib/src/btv_l1.cpp:357-457, on device-resident inputs
+ * with the handle's parameters.  y_host / rel_host: host arrays of K device
+ * pointers (float LR frames rows x cols x ch; relative motions rows x cols x
+ * 2).  out: device float (rows*scale-2B) x (cols*scale-2B) x ch; x_full:
+ * optional device float HR image before the crop (may be NULL). */
+SRX_API int srx_run(srx_handle* h, const float* const* y_host, const float* const* rel_host, int K, int base_idx,
+                    int rows, int cols, int ch, float* out, float* x_full);
+/* same, from n-1 consecutive forward motions: lib/src/btv_l1.cpp:328-355 */
+SRX_API int srx_process_device(srx_handle* h, const float* const* y_host, const float* const* fwd_motions_host, int K,
+                               int base_idx, int rows, int cols, int ch, float* out, float* x_full);
+/* Stream the handle launches on (hipStream_t), for callers that time or order work against it. */
+SRX_API void* srx_stream(srx_handle* h);
+/* Blocks until everything queued on the handle's stream has finished. */
+SRX_API int srx_synchronize(srx_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRX_H */

@@ -1,0 +1,1130 @@
+// C ABI of include/srx.h: handle, parameter table, streaming driver
+// (BTV_L1::initImpl / processImpl / addNewFrame / processFrame) and the
+// stage-level entry points.
+#include "srx_host.h"
+#include "srx_tvl1.h"
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+
+using namespace srx;
+
+namespace
+{
+
+size_t elem_size(int depth)
+{
+    return depth == SRX_8U ? 1 : 4;
+}
+
+int check_image(const srx_image& im, const char* what)
+{
+    if (!im.data || im.rows < 1 || im.cols < 1 || (im.depth != SRX_8U && im.depth != SRX_32F) || im.channels < 1 ||
+        im.channels > 4 || (im.mem != SRX_MEM_HOST && im.mem != SRX_MEM_DEVICE))
+    {
+        set_error(std::string(what) + ": malformed image header");
+        return SRX_ERR_INVALID;
+    }
+    const size_t rowbytes = (size_t)im.cols * im.channels * elem_size(im.depth);
+    if (im.step != 0 && im.step < rowbytes)
+    {
+        set_error(std::string(what) + ": step smaller than a row");
+        return SRX_ERR_INVALID;
+    }
+    return SRX_OK;
+}
+
+// dense copy of an image (host or device, any pitch) into device memory
+int copy_to_device(const srx_image& im, void* dst, hipStream_t st)
+{
+    const size_t rowbytes = (size_t)im.cols * im.channels * elem_size(im.depth);
+    const size_t step = im.step ? im.step : rowbytes;
+    SRX_HIP(hipMemcpy2DAsync(dst, rowbytes, im.data, step, rowbytes, im.rows,
+                             im.mem == SRX_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
+    return SRX_OK;
+}
+
+// dense device image -> caller image (host or device, any pitch)
+int copy_from_device(const void* src, const srx_image& im, hipStream_t st)
+{
+    const size_t rowbytes = (size_t)im.cols * im.channels * elem_size(im.depth);
+    const size_t step = im.step ? im.step : rowbytes;
+    SRX_HIP(hipMemcpy2DAsync(im.data, step, src, rowbytes, rowbytes, im.rows,
+                             im.mem == SRX_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+    return SRX_OK;
+}
+
+struct Event
+{
+    int v[5];
+};
+
+} // namespace
+
+struct srx_handle
+{
+    int device = -1;
+    bool dry = false;
+    hipStream_t stream = nullptr;
+    Params p;
+
+    // optical flow plug-in
+    int flow_kind = SRX_FLOW_NONE;
+    srx_flow_fn flow_fn = nullptr;
+    void* flow_user = nullptr;
+    Tvl1Params flow_params;
+    Tvl1 tvl1;
+
+    // frame source
+    srx_next_frame_fn next = nullptr;
+    srx_reset_fn reset = nullptr;
+    void* user = nullptr;
+    bool firstCall = true;
+
+    // rings (lib/include/super_resolution.hpp:182-190)
+    std::vector<DeviceBuffer> frames, motions, results;
+    int storePos = -1, procPos = -1, outPos = -1;
+    int radius = 0; // temporalAreaRadius latched at initImpl (ring sizes are fixed there)
+    int rows = 0, cols = 0, ch = 0, depth = SRX_8U;
+
+    // prevFrame, kept the way the source delivered it
+    std::vector<uint8_t> prev_host;
+    DeviceBuffer prev_dev;
+    srx_image prev_hdr{};
+    DeviceBuffer staging, flow_dev, batch_out;
+    std::vector<DeviceBuffer> batch_frames, batch_motions;
+    PinnedBuffer dst_host;
+    int outputMemory = SRX_MEM_HOST;
+
+    int out_first = 0, out_last = -1; // first > last: unrestricted
+    bool trace = false;
+    std::vector<Event> events;
+
+    Solver solver;
+
+    void log(int type, int a = 0, int b = 0, int c = 0, int d = 0)
+    {
+        if (trace)
+            events.push_back(Event{{type, a, b, c, d}});
+    }
+    bool in_range(int idx) const { return out_first > out_last || (idx >= out_first && idx <= out_last); }
+    int slot(int idx) const { return srx_ring_slot(idx, 2 * radius + 1); }
+    int set_device() const
+    {
+        if (!dry)
+            SRX_HIP(hipSetDevice(device));
+        return SRX_OK;
+    }
+
+    int to_float(const srx_image& im, float* dst);
+    int add_new_frame(const srx_image& frame);
+    int process_frame(int idx);
+    int init_impl();
+    int process_impl(srx_image* out, bool* produced);
+    int calc_flow(const srx_image& f0, const srx_image& f1, float* dst_dev);
+};
+
+// frame.convertTo(at(storePos, frames), CV_32F): lib/src/btv_l1.cpp:519
+int srx_handle::to_float(const srx_image& im, float* dst)
+{
+    const size_t count = (size_t)im.rows * im.cols * im.channels;
+    if (im.depth == SRX_32F)
+        return copy_to_device(im, dst, stream);
+    if (int rc = staging.reserve(count))
+        return rc;
+    if (int rc = copy_to_device(im, staging.get(), stream))
+        return rc;
+    return launch_convert_8u_to_32f(staging.as<uint8_t>(), count, dst, stream);
+}
+
+// opticalFlow->calc(frame0, frame1, flow): lib/src/btv_l1.cpp:315,522
+int srx_handle::calc_flow(const srx_image& f0, const srx_image& f1, float* dst)
+{
+    const size_t bytes = (size_t)f0.rows * f0.cols * 2 * sizeof(float);
+    if (flow_kind == SRX_FLOW_CALLBACK)
+    {
+        srx_image fl{};
+        if (flow_fn(flow_user, &f0, &f1, &fl) != 0)
+        {
+            set_error("optical-flow plug-in reported failure");
+            return SRX_ERR_FLOW;
+        }
+        if (dry)
+            return SRX_OK;
+        if (int rc = check_image(fl, "flow plug-in result"))
+            return rc;
+        if (fl.rows != f0.rows || fl.cols != f0.cols || fl.channels != 2 || fl.depth != SRX_32F)
+        {
+            set_error("flow plug-in result must be rows x cols x 2 float");
+            return SRX_ERR_FLOW;
+        }
+        (void)bytes;
+        return copy_to_device(fl, dst, stream);
+    }
+    if (flow_kind == SRX_FLOW_TVL1)
+    {
+        if (dry)
+            return SRX_OK;
+        return tvl1.calc_images(f0, f1, flow_params, dst, nullptr, stream);
+    }
+    set_error("no optical flow set (srx_set_flow_builtin / srx_set_flow_callback)");
+    return SRX_ERR_FLOW;
+}
+
+// BTV_L1::addNewFrame, lib/src/btv_l1.cpp:511-525
+int srx_handle::add_new_frame(const srx_image& frame)
+{
+    if (int rc = check_image(frame, "frame source"))
+        return rc;
+    if (frame.channels != 1 && frame.channels != 3)
+    {
+        set_error("frames must have 1 or 3 channels");
+        return SRX_ERR_INVALID;
+    }
+    if (storePos < 0)
+        rows = frame.rows, cols = frame.cols, ch = frame.channels, depth = frame.depth;
+    else if (frame.rows != rows || frame.cols != cols || frame.channels != ch || frame.depth != depth)
+    {
+        set_error("frame size or type changed within the stream");
+        return SRX_ERR_INVALID;
+    }
+    ++storePos;
+    const size_t px = (size_t)rows * cols;
+    if (!dry)
+    {
+        DeviceBuffer& f = frames[slot(storePos)];
+        if (int rc = f.reserve(px * ch * sizeof(float)))
+            return rc;
+        if (int rc = to_float(frame, f.as<float>()))
+            return rc;
+    }
+    if (storePos > 0)
+    {
+        log(SRX_EV_FLOW, storePos - 1);
+        float* dst = nullptr;
+        if (!dry)
+        {
+            DeviceBuffer& m = motions[slot(storePos - 1)];
+            if (int rc = m.reserve(px * 2 * sizeof(float)))
+                return rc;
+            dst = m.as<float>();
+        }
+        if (int rc = calc_flow(prev_hdr, frame, dst))
+            return rc;
+    }
+    // frame.copyTo(prevFrame)
+    const size_t rowbytes = (size_t)cols * ch * elem_size(depth);
+    prev_hdr = frame;
+    prev_hdr.step = rowbytes;
+    if (frame.mem == SRX_MEM_HOST)
+    {
+        prev_host.resize(rowbytes * rows);
+        const size_t step = frame.step ? frame.step : rowbytes;
+        for (int y = 0; y < rows; ++y)
+            std::memcpy(prev_host.data() + (size_t)y * rowbytes, (const uint8_t*)frame.data + (size_t)y * step,
+                        rowbytes);
+        prev_hdr.data = prev_host.data();
+    }
+    else if (!dry)
+    {
+        if (int rc = prev_dev.reserve(rowbytes * rows))
+            return rc;
+        if (int rc = copy_to_device(frame, prev_dev.get(), stream))
+            return rc;
+        prev_hdr.data = prev_dev.get();
+    }
+    return SRX_OK;
+}
+
+// BTV_L1::processFrame, lib/src/btv_l1.cpp:527-549
+int srx_handle::process_frame(int idx)
+{
+    if (!in_range(idx))
+        return SRX_OK;
+    int start, end, base;
+    srx_window(idx, radius, storePos, &start, &end, &base);
+    log(SRX_EV_SOLVE, idx, start, end, base);
+    if (dry)
+        return SRX_OK;
+    const float* y[kMaxWindow];
+    const float* fm[kMaxWindow];
+    const int K = end - start + 1;
+    for (int i = start, k = 0; i <= end; ++i, ++k)
+    {
+        y[k] = frames[slot(i)].as<float>();
+        if (i < end)
+            fm[k] = motions[slot(i)].as<float>();
+    }
+    if (int rc = solver.process(y, fm, K, base, rows, cols, ch, p, nullptr, nullptr, stream))
+        return rc;
+    // results ring keeps the cropped frame already converted to 8 bit; the
+    // reference converts at output time (lib/src/btv_l1.cpp:504), same values
+    const int R = rows * p.scale, C = cols * p.scale, B = p.btvKernelSize;
+    DeviceBuffer& res = results[slot(idx)];
+    if (int rc = res.reserve((size_t)(R - 2 * B) * (C - 2 * B) * ch))
+        return rc;
+    return launch_crop_convert(solver.last_x(), R, C, ch, B, res.get(), SRX_8U, stream);
+}
+
+// BTV_L1::initImpl, lib/src/btv_l1.cpp:466-488
+int srx_handle::init_impl()
+{
+    if (int rc = validate_params(p))
+        return rc;
+    radius = p.temporalAreaRadius;
+    const int cache = 2 * radius + 1;
+    frames.clear();
+    results.clear();
+    motions.clear();
+    frames.resize(cache);
+    results.resize(cache);
+    motions.resize(cache);
+    storePos = -1;
+    for (int t = -radius; t <= radius; ++t)
+    {
+        srx_image frame{};
+        const int got = next(user, &frame);
+        log(SRX_EV_READ, got ? 1 : 0);
+        if (!got)
+        {
+            set_error("frame source ended during warm-up (needs 2*temporalAreaRadius+1 frames)");
+            return SRX_ERR_SOURCE;
+        }
+        if (int rc = add_new_frame(frame))
+            return rc;
+    }
+    for (int i = 0; i <= radius; ++i)
+        if (int rc = process_frame(i))
+            return rc;
+    procPos = radius;
+    outPos = -1;
+    return SRX_OK;
+}
+
+// BTV_L1::processImpl, lib/src/btv_l1.cpp:490-509
+int srx_handle::process_impl(srx_image* out, bool* produced)
+{
+    *produced = false;
+    srx_image frame{};
+    const int got = next(user, &frame);
+    log(SRX_EV_READ, got ? 1 : 0);
+    if (got)
+        if (int rc = add_new_frame(frame))
+            return rc;
+    if (procPos < storePos)
+    {
+        ++procPos;
+        if (int rc = process_frame(procPos))
+            return rc;
+    }
+    if (outPos < storePos)
+    {
+        ++outPos;
+        *produced = true;
+        if (!in_range(outPos))
+            return SRX_OK;
+        log(SRX_EV_OUT, outPos);
+        const int B = p.btvKernelSize;
+        out->rows = rows * p.scale - 2 * B;
+        out->cols = cols * p.scale - 2 * B;
+        out->channels = ch;
+        out->depth = SRX_8U;
+        out->step = (size_t)out->cols * ch;
+        out->mem = outputMemory;
+        out->data = nullptr;
+        if (dry)
+            return SRX_OK;
+        const size_t bytes = (size_t)out->rows * out->step;
+        void* dev = results[slot(outPos)].get();
+        if (outputMemory == SRX_MEM_DEVICE)
+        {
+            out->data = dev;
+            SRX_HIP(hipStreamSynchronize(stream));
+            return SRX_OK;
+        }
+        if (int rc = dst_host.reserve(bytes))
+            return rc;
+        SRX_HIP(hipMemcpyAsync(dst_host.get(), dev, bytes, hipMemcpyDeviceToHost, stream));
+        SRX_HIP(hipStreamSynchronize(stream));
+        out->data = dst_host.get();
+    }
+    return SRX_OK;
+}
+
+// ===========================================================================
+extern "C"
+{
+
+SRX_API const char* srx_last_error(void)
+{
+    return last_error().c_str();
+}
+
+SRX_API int srx_create_btvl1(int device, srx_handle** out)
+{
+    if (!out)
+    {
+        set_error("srx_create_btvl1: out is NULL");
+        return SRX_ERR_INVALID;
+    }
+    *out = nullptr;
+    std::unique_ptr<srx_handle> h(new srx_handle);
+    h->device = device;
+    h->dry = device < 0;
+    if (!h->dry)
+    {
+        int n = 0;
+        SRX_HIP(hipGetDeviceCount(&n));
+        if (device >= n)
+        {
+            set_error("srx_create_btvl1: no such device");
+            return SRX_ERR_INVALID;
+        }
+        SRX_HIP(hipSetDevice(device));
+        SRX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    }
+    *out = h.release();
+    return SRX_OK;
+}
+
+SRX_API void srx_destroy(srx_handle* h)
+{
+    if (!h)
+        return;
+    if (!h->dry)
+    {
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->stream);
+    }
+    hipStream_t st = h->stream;
+    const bool dry = h->dry;
+    delete h;
+    if (!dry && st)
+        (void)hipStreamDestroy(st);
+}
+
+// ---- parameters -----------------------------------------------------------
+#define SRX_NEED(h)                                                                                                    \
+    if (!(h))                                                                                                          \
+    {                                                                                                                  \
+        set_error("handle is NULL");                                                                                   \
+        return SRX_ERR_INVALID;                                                                                        \
+    }
+
+static int* int_param(srx_handle* h, const std::string& n)
+{
+    if (n == "scale")
+        return &h->p.scale;
+    if (n == "iterations")
+        return &h->p.iterations;
+    if (n == "btvKernelSize")
+        return &h->p.btvKernelSize;
+    if (n == "blurKernelSize")
+        return &h->p.blurKernelSize;
+    if (n == "temporalAreaRadius")
+        return &h->p.temporalAreaRadius;
+    if (n == "outputMemory")
+        return &h->outputMemory;
+    return nullptr;
+}
+static double* double_param(srx_handle* h, const std::string& n)
+{
+    if (n == "tau")
+        return &h->p.tau;
+    if (n == "lambda")
+        return &h->p.lambda;
+    if (n == "alpha")
+        return &h->p.alpha;
+    if (n == "blurSigma")
+        return &h->p.blurSigma;
+    return nullptr;
+}
+
+SRX_API int srx_set_int(srx_handle* h, const char* name, int value)
+{
+    SRX_NEED(h);
+    const std::string n = name ? name : "";
+    if (n == "traceEvents")
+    {
+        h->trace = value != 0;
+        return SRX_OK;
+    }
+    if (int* p = int_param(h, n))
+    {
+        Params trial = h->p;
+        const int keep = *p;
+        *p = value;
+        if (n == "outputMemory")
+        {
+            if (value != SRX_MEM_HOST && value != SRX_MEM_DEVICE)
+            {
+                *p = keep;
+                set_error("outputMemory must be SRX_MEM_HOST or SRX_MEM_DEVICE");
+                return SRX_ERR_INVALID;
+            }
+            return SRX_OK;
+        }
+        if (int rc = validate_params(h->p))
+        {
+            h->p = trial;
+            return rc;
+        }
+        return SRX_OK;
+    }
+    if (double_param(h, n)) // Algorithm::set(name, int) on a double parameter converts
+        return srx_set_double(h, name, (double)value);
+    set_error("unknown int parameter: " + n);
+    return SRX_ERR_INVALID;
+}
+
+SRX_API int srx_set_double(srx_handle* h, const char* name, double value)
+{
+    SRX_NEED(h);
+    const std::string n = name ? name : "";
+    if (double* d = double_param(h, n))
+    {
+        const Params trial = h->p;
+        *d = value;
+        if (int rc = validate_params(h->p))
+        {
+            h->p = trial;
+            return rc;
+        }
+        return SRX_OK;
+    }
+    set_error("unknown double parameter: " + n);
+    return SRX_ERR_INVALID;
+}
+
+SRX_API int srx_get_int(srx_handle* h, const char* name, int* value)
+{
+    SRX_NEED(h);
+    const std::string n = name ? name : "";
+    if (!value)
+    {
+        set_error("value is NULL");
+        return SRX_ERR_INVALID;
+    }
+    if (n == "traceEvents")
+    {
+        *value = h->trace;
+        return SRX_OK;
+    }
+    if (int* p = int_param(h, n))
+    {
+        *value = *p;
+        return SRX_OK;
+    }
+    set_error("unknown int parameter: " + n);
+    return SRX_ERR_INVALID;
+}
+
+SRX_API int srx_get_double(srx_handle* h, const char* name, double* value)
+{
+    SRX_NEED(h);
+    const std::string n = name ? name : "";
+    if (!value)
+    {
+        set_error("value is NULL");
+        return SRX_ERR_INVALID;
+    }
+    if (double* d = double_param(h, n))
+    {
+        *value = *d;
+        return SRX_OK;
+    }
+    set_error("unknown double parameter: " + n);
+    return SRX_ERR_INVALID;
+}
+
+SRX_API int srx_set_flow_builtin(srx_handle* h, int kind)
+{
+    SRX_NEED(h);
+    if (kind != SRX_FLOW_NONE && kind != SRX_FLOW_TVL1)
+    {
+        set_error("unknown built-in flow");
+        return SRX_ERR_INVALID;
+    }
+    h->flow_kind = kind;
+    h->flow_fn = nullptr;
+    h->flow_user = nullptr;
+    return SRX_OK;
+}
+
+SRX_API int srx_set_flow_callback(srx_handle* h, srx_flow_fn fn, void* user)
+{
+    SRX_NEED(h);
+    if (!fn)
+    {
+        set_error("flow callback is NULL");
+        return SRX_ERR_INVALID;
+    }
+    h->flow_kind = SRX_FLOW_CALLBACK;
+    h->flow_fn = fn;
+    h->flow_user = user;
+    return SRX_OK;
+}
+
+SRX_API int srx_flow_set_int(srx_handle* h, const char* name, int value)
+{
+    SRX_NEED(h);
+    return tvl1_set_int(h->flow_params, name ? name : "", value);
+}
+SRX_API int srx_flow_set_double(srx_handle* h, const char* name, double value)
+{
+    SRX_NEED(h);
+    return tvl1_set_double(h->flow_params, name ? name : "", value);
+}
+SRX_API int srx_flow_get_int(srx_handle* h, const char* name, int* value)
+{
+    SRX_NEED(h);
+    return tvl1_get_int(h->flow_params, name ? name : "", value);
+}
+SRX_API int srx_flow_get_double(srx_handle* h, const char* name, double* value)
+{
+    SRX_NEED(h);
+    return tvl1_get_double(h->flow_params, name ? name : "", value);
+}
+
+// ---- streaming --------------------------------------------------------------
+SRX_API int srx_set_input(srx_handle* h, srx_next_frame_fn next, srx_reset_fn reset, void* user)
+{
+    SRX_NEED(h);
+    h->next = next;
+    h->reset = reset;
+    h->user = user;
+    h->firstCall = true;
+    return SRX_OK;
+}
+
+SRX_API int srx_reset(srx_handle* h)
+{
+    SRX_NEED(h);
+    if (h->reset)
+        h->reset(h->user);
+    h->firstCall = true;
+    return SRX_OK;
+}
+
+SRX_API int srx_set_output_range(srx_handle* h, int first, int last)
+{
+    SRX_NEED(h);
+    h->out_first = first;
+    h->out_last = last;
+    return SRX_OK;
+}
+
+SRX_API int srx_next_frame(srx_handle* h, srx_image* out)
+{
+    SRX_NEED(h);
+    if (!out)
+    {
+        set_error("out is NULL");
+        return SRX_ERR_INVALID;
+    }
+    std::memset(out, 0, sizeof(*out));
+    if (!h->next)
+    {
+        // the reference starts with a NullFrameSource, whose empty frame trips the
+        // warm-up assertion (lib/src/super_resolution.cpp:127, lib/src/btv_l1.cpp:479)
+        set_error("no frame source set");
+        return SRX_ERR_SOURCE;
+    }
+    if (int rc = h->set_device())
+        return rc;
+    if (h->firstCall)
+    {
+        if (int rc = h->init_impl())
+            return rc;
+        h->firstCall = false;
+    }
+    for (;;)
+    {
+        if (h->out_first <= h->out_last && h->outPos >= h->out_last)
+            return SRX_OK; // span finished: empty frame
+        bool produced = false;
+        if (int rc = h->process_impl(out, &produced))
+            return rc;
+        if (!produced)
+            return SRX_OK; // end of stream
+        if (h->in_range(h->outPos))
+            return SRX_OK;
+    }
+}
+
+SRX_API int srx_drain_events(srx_handle* h, int* buf, int max_events)
+{
+    if (!h || !buf || max_events < 0)
+        return 0;
+    const int n = std::min<int>(max_events, (int)h->events.size());
+    for (int i = 0; i < n; ++i)
+        std::memcpy(buf + 5 * i, h->events[i].v, sizeof(int) * 5);
+    h->events.erase(h->events.begin(), h->events.begin() + n);
+    return n;
+}
+
+// ---- batch -------------------------------------------------------------------
+SRX_API int srx_process(srx_handle* h, const srx_image* frames, int n, const srx_image* motions, int base_idx,
+                        srx_image* out)
+{
+    SRX_NEED(h);
+    if (h->dry)
+    {
+        set_error("srx_process needs a GPU handle");
+        return SRX_ERR_STATE;
+    }
+    if (!frames || !out || n < 1 || n > kMaxWindow || base_idx < 0 || base_idx >= n)
+    {
+        set_error("srx_process: bad frame list or base index");
+        return SRX_ERR_INVALID;
+    }
+    if (int rc = h->set_device())
+        return rc;
+    if (int rc = validate_params(h->p))
+        return rc;
+    const srx_image& f0 = frames[0];
+    for (int i = 0; i < n; ++i)
+    {
+        if (int rc = check_image(frames[i], "srx_process frame"))
+            return rc;
+        if (frames[i].rows != f0.rows || frames[i].cols != f0.cols || frames[i].channels != f0.channels ||
+            frames[i].depth != f0.depth)
+        {
+            set_error("srx_process: frames differ in size or type");
+            return SRX_ERR_INVALID;
+        }
+    }
+    if (f0.channels != 1 && f0.channels != 3)
+    {
+        set_error("frames must have 1 or 3 channels");
+        return SRX_ERR_INVALID;
+    }
+    const int rows = f0.rows, cols = f0.cols, ch = f0.channels;
+    const size_t px = (size_t)rows * cols;
+    if ((int)h->batch_frames.size() < n)
+    {
+        h->batch_frames.resize(n);
+        h->batch_motions.resize(n);
+    }
+    const float* y[kMaxWindow];
+    const float* m[kMaxWindow];
+    for (int i = 0; i < n; ++i)
+    {
+        if (int rc = h->batch_frames[i].reserve(px * ch * sizeof(float)))
+            return rc;
+        if (int rc = h->to_float(frames[i], h->batch_frames[i].as<float>()))
+            return rc;
+        y[i] = h->batch_frames[i].as<float>();
+    }
+    const int B = h->p.btvKernelSize, s = h->p.scale;
+    const int orows = rows * s - 2 * B, ocols = cols * s - 2 * B;
+    if (int rc = check_image(*out, "srx_process out"))
+        return rc;
+    if (out->rows != orows || out->cols != ocols || out->channels != ch || out->depth != f0.depth)
+    {
+        set_error("srx_process: out must be (rows*scale-2B) x (cols*scale-2B) with the frames' type");
+        return SRX_ERR_INVALID;
+    }
+    int rc;
+    if (motions)
+    {
+        for (int i = 0; i < n - 1; ++i)
+        {
+            if ((rc = check_image(motions[i], "srx_process motion")))
+                return rc;
+            if (motions[i].rows != rows || motions[i].cols != cols || motions[i].channels != 2 ||
+                motions[i].depth != SRX_32F)
+            {
+                set_error("srx_process: motions must be rows x cols x 2 float");
+                return SRX_ERR_INVALID;
+            }
+            if ((rc = h->batch_motions[i].reserve(px * 2 * sizeof(float))))
+                return rc;
+            if ((rc = copy_to_device(motions[i], h->batch_motions[i].get(), h->stream)))
+                return rc;
+            m[i] = h->batch_motions[i].as<float>();
+        }
+        rc = h->solver.process(y, m, n, base_idx, rows, cols, ch, h->p, nullptr, nullptr, h->stream);
+    }
+    else
+    {
+        // flow frame i -> base for every i != base, zero for the base (lib/src/btv_l1.cpp:311-321)
+        for (int i = 0; i < n; ++i)
+        {
+            if ((rc = h->batch_motions[i].reserve(px * 2 * sizeof(float))))
+                return rc;
+            if (i == base_idx)
+                SRX_HIP(hipMemsetAsync(h->batch_motions[i].get(), 0, px * 2 * sizeof(float), h->stream));
+            else if ((rc = h->calc_flow(frames[i], frames[base_idx], h->batch_motions[i].as<float>())))
+                return rc;
+            m[i] = h->batch_motions[i].as<float>();
+        }
+        rc = h->solver.run(y, m, n, base_idx, rows, cols, ch, h->p, nullptr, nullptr, h->stream);
+    }
+    if (rc)
+        return rc;
+    const size_t obytes = (size_t)orows * ocols * ch * elem_size(f0.depth);
+    if ((rc = h->batch_out.reserve(obytes)))
+        return rc;
+    if ((rc = launch_crop_convert(h->solver.last_x(), rows * s, cols * s, ch, B, h->batch_out.get(), f0.depth,
+                                  h->stream)))
+        return rc;
+    if ((rc = copy_from_device(h->batch_out.get(), *out, h->stream)))
+        return rc;
+    SRX_HIP(hipStreamSynchronize(h->stream));
+    return SRX_OK;
+}
+
+SRX_API int srx_flow_calc(srx_handle* h, const srx_image* frame0, const srx_image* frame1, srx_image* flow1,
+                          srx_image* flow2)
+{
+    SRX_NEED(h);
+    if (h->dry)
+    {
+        set_error("srx_flow_calc needs a GPU handle");
+        return SRX_ERR_STATE;
+    }
+    if (!frame0 || !frame1 || !flow1)
+    {
+        set_error("srx_flow_calc: NULL argument");
+        return SRX_ERR_INVALID;
+    }
+    if (int rc = h->set_device())
+        return rc;
+    if (int rc = check_image(*frame0, "flow frame0"))
+        return rc;
+    if (int rc = check_image(*frame1, "flow frame1"))
+        return rc;
+    if (frame0->rows != frame1->rows || frame0->cols != frame1->cols || frame0->channels != frame1->channels ||
+        frame0->depth != frame1->depth)
+    {
+        set_error("srx_flow_calc: frames differ in size or type");
+        return SRX_ERR_INVALID;
+    }
+    const int rows = frame0->rows, cols = frame0->cols;
+    const size_t px = (size_t)rows * cols;
+    if (int rc = h->flow_dev.reserve(px * 2 * sizeof(float)))
+        return rc;
+    if (int rc = h->calc_flow(*frame0, *frame1, h->flow_dev.as<float>()))
+        return rc;
+    if (int rc = check_image(*flow1, "flow1"))
+        return rc;
+    if (!flow2)
+    {
+        if (flow1->rows != rows || flow1->cols != cols || flow1->channels != 2 || flow1->depth != SRX_32F)
+        {
+            set_error("flow1 must be rows x cols x 2 float");
+            return SRX_ERR_INVALID;
+        }
+        if (int rc = copy_from_device(h->flow_dev.get(), *flow1, h->stream))
+            return rc;
+    }
+    else
+    {
+        // planar u, v (lib/src/optical_flow.cpp:77-80)
+        if (int rc = check_image(*flow2, "flow2"))
+            return rc;
+        for (const srx_image* f : {flow1, flow2})
+            if (f->rows != rows || f->cols != cols || f->channels != 1 || f->depth != SRX_32F)
+            {
+                set_error("flow1/flow2 must be rows x cols x 1 float");
+                return SRX_ERR_INVALID;
+            }
+        if (int rc = h->staging.reserve(px * 2 * sizeof(float)))
+            return rc;
+        float* u = h->staging.as<float>();
+        float* v = u + px;
+        if (int rc = launch_split2(h->flow_dev.as<float>(), px, u, v, h->stream))
+            return rc;
+        if (int rc = copy_from_device(u, *flow1, h->stream))
+            return rc;
+        if (int rc = copy_from_device(v, *flow2, h->stream))
+            return rc;
+    }
+    SRX_HIP(hipStreamSynchronize(h->stream));
+    return SRX_OK;
+}
+
+SRX_API int srx_collect_garbage(srx_handle* h)
+{
+    SRX_NEED(h);
+    if (h->dry)
+        return SRX_OK;
+    if (int rc = h->set_device())
+        return rc;
+    SRX_HIP(hipStreamSynchronize(h->stream));
+    h->tvl1.release();
+    h->staging.release();
+    h->flow_dev.release();
+    h->batch_out.release();
+    h->batch_frames.clear();
+    h->batch_motions.clear();
+    return SRX_OK;
+}
+
+SRX_API void* srx_stream(srx_handle* h)
+{
+    return h ? (void*)h->stream : nullptr;
+}
+
+SRX_API int srx_synchronize(srx_handle* h)
+{
+    SRX_NEED(h);
+    if (h->dry)
+        return SRX_OK;
+    SRX_HIP(hipSetDevice(h->device));
+    SRX_HIP(hipStreamSynchronize(h->stream));
+    return SRX_OK;
+}
+
+// ---- pure host helpers ---------------------------------------------------------
+SRX_API int srx_ring_slot(int index, int size)
+{
+    if (size <= 0)
+        return 0;
+    int m = index % size;
+    return m < 0 ? m + size : m;
+}
+
+SRX_API void srx_window(int idx, int radius, int store_pos, int* start, int* end, int* base)
+{
+    const int s = std::max(idx - radius, 0);
+    const int e = std::min(s + 2 * radius, store_pos);
+    if (start)
+        *start = s;
+    if (end)
+        *end = e;
+    if (base)
+        *base = idx - s;
+}
+
+SRX_API int srx_calc_btv_weights(int btv_kernel_size, double alpha, float* w)
+{
+    if (btv_kernel_size < 1 || !w)
+        return 0;
+    return calc_btv_weights(btv_kernel_size, alpha, w);
+}
+
+SRX_API int srx_gaussian_kernel(int n, double sigma, float* k)
+{
+    if (!k)
+    {
+        set_error("k is NULL");
+        return SRX_ERR_INVALID;
+    }
+    return gaussian_kernel(n, sigma, k);
+}
+
+SRX_API int srx_span_plan(int total_frames, int radius, int world, int rank, int* out_first, int* out_last,
+                          int* in_first, int* in_last)
+{
+    if (total_frames < 1 || radius < 0 || world < 1 || rank < 0 || rank >= world)
+    {
+        set_error("srx_span_plan: bad arguments");
+        return SRX_ERR_INVALID;
+    }
+    // contiguous spans, the first (total % world) ranks get one frame more
+    const int q = total_frames / world, r = total_frames % world;
+    const int a = rank * q + std::min(rank, r);
+    const int b = a + q + (rank < r ? 1 : 0) - 1; // may be a-1 (empty span) when world > total
+    if (out_first)
+        *out_first = a;
+    if (out_last)
+        *out_last = b;
+    if (in_first)
+        *in_first = std::max(a - radius, 0);
+    if (in_last)
+        *in_last = std::min(std::max(b, a) + radius, total_frames - 1);
+    return SRX_OK;
+}
+
+// ---- stage-level device entry points ---------------------------------------------
+SRX_API int srx_k_relative_motions(const float* const* fwd_host, float* const* rel_host, int n, int base_idx, int rows,
+                                   int cols, void* stream)
+{
+    if (!rel_host || n < 1 || n > kMaxWindow || base_idx < 0 || base_idx >= n || (n > 1 && !fwd_host))
+    {
+        set_error("srx_k_relative_motions: bad arguments");
+        return SRX_ERR_INVALID;
+    }
+    PtrList f{};
+    MutPtrList r{};
+    for (int i = 0; i < n; ++i)
+    {
+        if (i < n - 1)
+            f.p[i] = fwd_host[i];
+        r.p[i] = rel_host[i];
+    }
+    return launch_relative_motions(f, r, n, base_idx, (size_t)rows * cols * 2, (hipStream_t)stream);
+}
+
+SRX_API int srx_k_build_maps(const float* rel, int rows, int cols, int scale, int16_t* fwd_map, int16_t* bwd_map,
+                             void* stream)
+{
+    if (!rel || !fwd_map || !bwd_map || rows < 1 || cols < 1 || scale < 2 || (long)rows * scale > 32767 ||
+        (long)cols * scale > 32767)
+    {
+        set_error("srx_k_build_maps: bad arguments");
+        return SRX_ERR_INVALID;
+    }
+    CubicTablesDev t;
+    if (int rc = t.ensure(rows, cols, rows * scale, cols * scale, (hipStream_t)stream))
+        return rc;
+    if (int rc = launch_build_maps(rel, rows, cols, scale, t.view(), fwd_map, bwd_map, (hipStream_t)stream))
+        return rc;
+    SRX_HIP(hipStreamSynchronize((hipStream_t)stream)); // the tables die with this call
+    return SRX_OK;
+}
+
+SRX_API int srx_k_resize_cubic(const float* src, int srows, int scols, int ch, float* dst, int drows, int dcols,
+                               void* stream)
+{
+    if (!src || !dst || srows < 1 || scols < 1 || drows < 1 || dcols < 1)
+    {
+        set_error("srx_k_resize_cubic: bad arguments");
+        return SRX_ERR_INVALID;
+    }
+    CubicTablesDev t;
+    if (int rc = t.ensure(srows, scols, drows, dcols, (hipStream_t)stream))
+        return rc;
+    if (int rc = launch_resize_cubic(src, srows, scols, ch, t.view(), dst, drows, dcols, (hipStream_t)stream))
+        return rc;
+    SRX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return SRX_OK;
+}
+
+static int make_btv(int btv_kernel_size, const float* w_host, BtvW& bw)
+{
+    const int radius = (btv_kernel_size - 1) / 2;
+    if (btv_kernel_size < 1 || radius > kMaxBtvRadius || !w_host)
+    {
+        set_error("btvKernelSize must be in 1..16 and weights non-NULL");
+        return SRX_ERR_INVALID;
+    }
+    std::memset(&bw, 0, sizeof(bw));
+    bw.radius = radius;
+    int cnt = 0;
+    for (int m = 0; m <= radius; ++m)
+        cnt += radius + m + 1;
+    std::memcpy(bw.w, w_host, sizeof(float) * cnt);
+    return SRX_OK;
+}
+
+static int make_gauss(const float* gauss_host, int n, GaussK& g)
+{
+    if (!gauss_host || n < 1 || n > kMaxGauss || (n & 1) == 0)
+    {
+        set_error("gauss kernel must be odd, 1..31 taps");
+        return SRX_ERR_INVALID;
+    }
+    std::memset(&g, 0, sizeof(g));
+    g.n = n;
+    std::memcpy(g.k, gauss_host, sizeof(float) * n);
+    return SRX_OK;
+}
+
+SRX_API int srx_k_btv_regularization(const float* src, int rows, int cols, int ch, int btv_kernel_size,
+                                     const float* w_host, float* dst, void* stream)
+{
+    if (!src || !dst || rows < 1 || cols < 1)
+    {
+        set_error("srx_k_btv_regularization: bad arguments");
+        return SRX_ERR_INVALID;
+    }
+    BtvW bw;
+    if (int rc = make_btv(btv_kernel_size, w_host, bw))
+        return rc;
+    return launch_btv_regularization(src, rows, cols, ch, bw, dst, (hipStream_t)stream);
+}
+
+SRX_API int srx_k_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const int16_t* bwd_map,
+                               const float* y, int scale, const float* gauss_host, int gauss_n, int8_t* sign_out,
+                               void* stream)
+{
+    if (!X || !bwd_map || !y || !sign_out || scale < 2 || hr_rows < scale || hr_cols < scale ||
+        hr_rows % scale || hr_cols % scale || hr_rows > 32767 || hr_cols > 32767)
+    {
+        set_error("srx_k_forward_sign: bad arguments");
+        return SRX_ERR_INVALID;
+    }
+    GaussK g;
+    if (int rc = make_gauss(gauss_host, gauss_n, g))
+        return rc;
+    PtrList maps{}, ys{};
+    MutPtrList sg{};
+    maps.p[0] = bwd_map;
+    ys.p[0] = y;
+    sg.p[0] = sign_out;
+    return launch_forward_sign(X, hr_rows, hr_cols, ch, maps, ys, sg, 1, scale, g, (hipStream_t)stream);
+}
+
+SRX_API int srx_k_backproject_update(const float* X, float* X_out, int hr_rows, int hr_cols, int ch,
+                                     const int16_t* const* fwd_maps_host, const int8_t* const* signs_host, int K,
+                                     int scale, const float* gauss_host, int gauss_n, int btv_kernel_size,
+                                     const float* w_host, double tau, double lambda, void* stream)
+{
+    if (!X || !X_out || X == X_out || !fwd_maps_host || !signs_host || K < 0 || K > kMaxWindow || scale < 2 ||
+        hr_rows % scale || hr_cols % scale || hr_rows < scale || hr_cols < scale || hr_rows > 32767 ||
+        hr_cols > 32767)
+    {
+        set_error("srx_k_backproject_update: bad arguments");
+        return SRX_ERR_INVALID;
+    }
+    GaussK g;
+    if (int rc = make_gauss(gauss_host, gauss_n, g))
+        return rc;
+    BtvW bw;
+    if (int rc = make_btv(btv_kernel_size, w_host, bw))
+        return rc;
+    PtrList maps{}, sg{};
+    for (int k = 0; k < K; ++k)
+    {
+        maps.p[k] = fwd_maps_host[k];
+        sg.p[k] = signs_host[k];
+    }
+    return launch_backproject_update(X, X_out, hr_rows, hr_cols, ch, maps, sg, K, scale, g, bw, tau, lambda,
+                                     (hipStream_t)stream);
+}
+
+SRX_API int srx_k_crop_convert(const float* X, int rows, int cols, int ch, int border, void* dst, int depth,
+                               void* stream)
+{
+    if (!X || !dst || border < 0 || rows - 2 * border < 1 || cols - 2 * border < 1 ||
+        (depth != SRX_8U && depth != SRX_32F))
+    {
+        set_error("srx_k_crop_convert: bad arguments");
+        return SRX_ERR_INVALID;
+    }
+    return launch_crop_convert(X, rows, cols, ch, border, dst, depth, (hipStream_t)stream);
+}
+
+SRX_API int srx_run(srx_handle* h, const float* const* y_host, const float* const* rel_host, int K, int base_idx,
+                    int rows, int cols, int ch, float* out, float* x_full)
+{
+    SRX_NEED(h);
+    if (h->dry || !y_host || !rel_host)
+    {
+        set_error("srx_run: needs a GPU handle and non-NULL pointer lists");
+        return SRX_ERR_INVALID;
+    }
+    if (int rc = h->set_device())
+        return rc;
+    return h->solver.run(y_host, rel_host, K, base_idx, rows, cols, ch, h->p, out, x_full, h->stream);
+}
+
+SRX_API int srx_process_device(srx_handle* h, const float* const* y_host, const float* const* fwd_motions_host, int K,
+                               int base_idx, int rows, int cols, int ch, float* out, float* x_full)
+{
+    SRX_NEED(h);
+    if (h->dry || !y_host || (K > 1 && !fwd_motions_host))
+    {
+        set_error("srx_process_device: needs a GPU handle and non-NULL pointer lists");
+        return SRX_ERR_INVALID;
+    }
+    if (int rc = h->set_device())
+        return rc;
+    return h->solver.process(y_host, fwd_motions_host, K, base_idx, rows, cols, ch, h->p, out, x_full, h->stream);
+}
+
+} // extern "C"

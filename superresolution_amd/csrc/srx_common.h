@@ -1,0 +1,75 @@
+// Internal declarations shared by the host driver and the HIP kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+namespace srx
+{
+
+constexpr int kMaxWindow = 40;      // frames per temporal window (2*radius+1 <= 40)
+constexpr int kMaxGauss = 31;       // largest blur kernel size
+constexpr int kMaxBtvRadius = 7;    // btvKernelSize <= 15
+constexpr int kMaxBtvWeights = 96;  // sum_{m=0..7} (7+m+1) = 92
+
+// Kernel argument blocks passed by value.
+struct PtrList
+{
+    const void* p[kMaxWindow];
+};
+struct MutPtrList
+{
+    void* p[kMaxWindow];
+};
+struct GaussK
+{
+    float k[kMaxGauss + 1];
+    int n;
+};
+struct BtvW
+{
+    float w[kMaxBtvWeights];
+    int radius; // (btvKernelSize - 1) / 2
+};
+
+// Host-built tap tables of cv::resize(INTER_CUBIC): per destination column /
+// row the source index of tap 1 and the four weights.
+struct CubicTables
+{
+    const int* xofs;
+    const float4* alpha;
+    const int* yofs;
+    const float4* beta;
+};
+
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+
+#define SRX_HIP(call)                                                                                                  \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        hipError_t e__ = (call);                                                                                       \
+        if (e__ != hipSuccess)                                                                                         \
+            return ::srx::hip_fail(e__, #call);                                                                        \
+    } while (0)
+
+// ---- launchers (srx_kernels.hip) -----------------------------------------
+int launch_relative_motions(const PtrList& fwd, const MutPtrList& rel, int n, int base_idx, size_t count,
+                            hipStream_t st);
+int launch_build_maps(const float* rel, int rows, int cols, int scale, const CubicTables& t, int16_t* fwd_map,
+                      int16_t* bwd_map, hipStream_t st);
+int launch_resize_cubic(const float* src, int srows, int scols, int ch, const CubicTables& t, float* dst, int drows,
+                        int dcols, hipStream_t st);
+int launch_btv_regularization(const float* src, int rows, int cols, int ch, const BtvW& w, float* dst, hipStream_t st);
+// sign(y_k - D H M_k X) for K frames in one launch
+int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const PtrList& bwd_maps, const PtrList& y,
+                        const MutPtrList& signs, int K, int scale, const GaussK& g, hipStream_t st);
+int launch_backproject_update(const float* X, float* X_out, int hr_rows, int hr_cols, int ch, const PtrList& fwd_maps,
+                              const PtrList& signs, int K, int scale, const GaussK& g, const BtvW& w, double tau,
+                              double lambda, hipStream_t st);
+int launch_crop_convert(const float* X, int rows, int cols, int ch, int border, void* dst, int depth, hipStream_t st);
+int launch_convert_8u_to_32f(const uint8_t* src, size_t count, float* dst, hipStream_t st);
+
+} // namespace srx

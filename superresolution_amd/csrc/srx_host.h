@@ -1,0 +1,126 @@
+// Host-side classes of the srx library: device buffers, the BTV-L1 solver and
+// the streaming driver behind the C ABI of include/srx.h.
+#pragma once
+
+#include "srx_common.h"
+#include "../../include/srx.h"
+
+#include <array>
+#include <memory>
+#include <vector>
+
+namespace srx
+{
+
+// Grow-only device allocation bound to the device that was current at the
+// first reserve().
+class DeviceBuffer
+{
+  public:
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer&) = delete;
+    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    DeviceBuffer(DeviceBuffer&& o) noexcept : ptr_(o.ptr_), cap_(o.cap_) { o.ptr_ = nullptr, o.cap_ = 0; }
+    DeviceBuffer& operator=(DeviceBuffer&& o) noexcept
+    {
+        if (this != &o)
+        {
+            release();
+            ptr_ = o.ptr_, cap_ = o.cap_;
+            o.ptr_ = nullptr, o.cap_ = 0;
+        }
+        return *this;
+    }
+    ~DeviceBuffer() { release(); }
+    int reserve(size_t bytes);
+    void release();
+    template <typename T> T* as() const { return static_cast<T*>(ptr_); }
+    void* get() const { return ptr_; }
+    size_t capacity() const { return cap_; }
+
+  private:
+    void* ptr_ = nullptr;
+    size_t cap_ = 0;
+};
+
+class PinnedBuffer
+{
+  public:
+    PinnedBuffer() = default;
+    PinnedBuffer(const PinnedBuffer&) = delete;
+    PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+    ~PinnedBuffer() { release(); }
+    int reserve(size_t bytes);
+    void release();
+    void* get() const { return ptr_; }
+
+  private:
+    void* ptr_ = nullptr;
+    size_t cap_ = 0;
+};
+
+// Parameters of BTV_L1_Base / BTV_L1 (lib/include/super_resolution.hpp:54-62,172)
+struct Params
+{
+    int scale = 4;
+    int iterations = 180;
+    double tau = 1.3;
+    double lambda = 0.03;
+    double alpha = 0.7;
+    int btvKernelSize = 7;
+    int blurKernelSize = 5;
+    double blurSigma = 0.0;
+    int temporalAreaRadius = 4;
+};
+
+const std::string& last_error();
+
+// Validates what the reference only debug-asserts (lib/src/btv_l1.cpp:359-365).
+int validate_params(const Params& p);
+
+// Host-built cv::resize(INTER_CUBIC) tap tables
+void cubic_table_x(int scols, int dcols, std::vector<int>& sx, std::vector<float>& alpha);
+void cubic_table_y(int srows, int drows, std::vector<int>& sy, std::vector<float>& beta);
+int gaussian_kernel(int n, double sigma, float* k);
+int calc_btv_weights(int btv_kernel_size, double alpha, float* w);
+
+// Device copy of the tap tables for one (src, dst) geometry.
+class CubicTablesDev
+{
+  public:
+    int ensure(int srows, int scols, int drows, int dcols, hipStream_t st);
+    CubicTables view() const;
+
+  private:
+    int srows_ = 0, scols_ = 0, drows_ = 0, dcols_ = 0;
+    DeviceBuffer xofs_, alpha_, yofs_, beta_;
+};
+
+// BTV_L1_Base::run on device-resident inputs (lib/src/btv_l1.cpp:357-457).
+class Solver
+{
+  public:
+    int run(const float* const* y, const float* const* rel, int K, int base_idx, int rows, int cols, int ch,
+            const Params& p, float* out, float* x_full, hipStream_t st);
+    int process(const float* const* y, const float* const* fwd_motions, int K, int base_idx, int rows, int cols,
+                int ch, const Params& p, float* out, float* x_full, hipStream_t st);
+    // HR image after the last run (device), rows*scale x cols*scale x ch
+    const float* last_x() const { return x_[cur_].as<float>(); }
+    void release();
+
+  private:
+    int ensure(int K, int rows, int cols, int ch, int scale, hipStream_t st);
+    std::vector<DeviceBuffer> fwd_maps_, bwd_maps_, signs_, rel_;
+    DeviceBuffer x_[2];
+    int cur_ = 0;
+    CubicTablesDev tables_;
+    // cached filter / weights, re-derived on parameter change (lib/src/btv_l1.cpp:392-405)
+    GaussK gauss_{};
+    int curBlurKernelSize_ = -1;
+    double curBlurSigma_ = -1.0;
+    BtvW btv_{};
+    int curBtvKernelSize_ = -1;
+    double curAlpha_ = -1.0;
+};
+
+} // namespace srx

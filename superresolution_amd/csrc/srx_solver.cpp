@@ -1,0 +1,369 @@
+// Host helpers and the BTV-L1 solver (host side of BTV_L1_Base::run).
+#include "srx_host.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace srx
+{
+
+namespace
+{
+thread_local std::string g_error;
+}
+
+void set_error(const std::string& msg)
+{
+    g_error = msg;
+}
+const std::string& last_error()
+{
+    return g_error;
+}
+int hip_fail(hipError_t e, const char* what)
+{
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return SRX_ERR_DEVICE;
+}
+
+// ---------------------------------------------------------------------------
+int DeviceBuffer::reserve(size_t bytes)
+{
+    if (bytes <= cap_)
+        return 0;
+    release();
+    SRX_HIP(hipMalloc(&ptr_, bytes));
+    cap_ = bytes;
+    return 0;
+}
+void DeviceBuffer::release()
+{
+    if (ptr_)
+        (void)hipFree(ptr_);
+    ptr_ = nullptr;
+    cap_ = 0;
+}
+int PinnedBuffer::reserve(size_t bytes)
+{
+    if (bytes <= cap_)
+        return 0;
+    release();
+    SRX_HIP(hipHostMalloc(&ptr_, bytes, hipHostMallocDefault));
+    cap_ = bytes;
+    return 0;
+}
+void PinnedBuffer::release()
+{
+    if (ptr_)
+        (void)hipHostFree(ptr_);
+    ptr_ = nullptr;
+    cap_ = 0;
+}
+
+// ---------------------------------------------------------------------------
+int validate_params(const Params& p)
+{
+    auto bad = [](const char* m) {
+        set_error(m);
+        return (int)SRX_ERR_INVALID;
+    };
+    if (p.scale < 2 || p.scale > 16)
+        return bad("scale must be in 2..16");
+    if (p.iterations < 1)
+        return bad("iterations must be positive");
+    if (!(p.tau > 0.0))
+        return bad("tau must be positive");
+    if (!(p.alpha > 0.0))
+        return bad("alpha must be positive");
+    if (p.btvKernelSize < 1 || (p.btvKernelSize - 1) / 2 > kMaxBtvRadius)
+        return bad("btvKernelSize must be in 1..16");
+    if (p.blurKernelSize < 1 || p.blurKernelSize > kMaxGauss || (p.blurKernelSize & 1) == 0)
+        return bad("blurKernelSize must be odd and in 1..31");
+    if (!(p.blurSigma >= 0.0))
+        return bad("blurSigma must be non-negative");
+    if (p.temporalAreaRadius < 0 || 2 * p.temporalAreaRadius + 1 > kMaxWindow)
+        return bad("temporalAreaRadius must be in 0..19");
+    return SRX_OK;
+}
+
+// interpolateCubic of OpenCV's imgwarp.cpp (A = -0.75), float arithmetic
+static void cubic_coeffs(float x, float* c)
+{
+    const float A = -0.75f;
+    c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+// cv::resize tap set-up.  Columns whose tap 1 would fall outside [0, cols-1)
+// are snapped to a plain copy, as OpenCV 2.4 does; rows are only clipped.
+void cubic_table_x(int scols, int dcols, std::vector<int>& sx, std::vector<float>& alpha)
+{
+    sx.resize(dcols);
+    alpha.resize((size_t)dcols * 4);
+    const double scale = 1.0 / ((double)dcols / scols);
+    for (int dx = 0; dx < dcols; ++dx)
+    {
+        float fx = (float)((dx + 0.5) * scale - 0.5);
+        int s = (int)std::floor((double)fx);
+        fx -= s;
+        if (s < 0)
+            fx = 0, s = 0;
+        if (s >= scols - 1)
+            fx = 0, s = scols - 1;
+        sx[dx] = s;
+        cubic_coeffs(fx, &alpha[(size_t)dx * 4]);
+    }
+}
+
+void cubic_table_y(int srows, int drows, std::vector<int>& sy, std::vector<float>& beta)
+{
+    sy.resize(drows);
+    beta.resize((size_t)drows * 4);
+    const double scale = 1.0 / ((double)drows / srows);
+    for (int dy = 0; dy < drows; ++dy)
+    {
+        float fy = (float)((dy + 0.5) * scale - 0.5);
+        const int s = (int)std::floor((double)fy);
+        fy -= s;
+        sy[dy] = s;
+        cubic_coeffs(fy, &beta[(size_t)dy * 4]);
+    }
+}
+
+// cv::getGaussianKernel(n, sigma, CV_32F)
+int gaussian_kernel(int n, double sigma, float* k)
+{
+    if (n < 1 || n > kMaxGauss || (n & 1) == 0)
+    {
+        set_error("gaussian kernel size must be odd and in 1..31");
+        return SRX_ERR_INVALID;
+    }
+    static const float tab[4][7] = {{1.f},
+                                    {0.25f, 0.5f, 0.25f},
+                                    {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f},
+                                    {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f}};
+    const float* fixed = (n <= 7 && sigma <= 0) ? tab[n >> 1] : nullptr;
+    const double sigmaX = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+    const double scale2X = -0.5 / (sigmaX * sigmaX);
+    double sum = 0;
+    for (int i = 0; i < n; ++i)
+    {
+        const double x = i - (n - 1) * 0.5;
+        const double t = fixed ? (double)fixed[i] : std::exp(scale2X * x * x);
+        k[i] = (float)t;
+        sum += k[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < n; ++i)
+        k[i] = (float)(k[i] * sum);
+    return SRX_OK;
+}
+
+// calcBtvWeights (lib/src/btv_l1.cpp:172-189)
+int calc_btv_weights(int btv_kernel_size, double alpha, float* w)
+{
+    const int ksize = (btv_kernel_size - 1) / 2;
+    const float alpha_f = (float)alpha;
+    int ind = 0;
+    for (int m = 0; m <= ksize; ++m)
+        for (int l = ksize; l + m >= 0; --l, ++ind)
+            w[ind] = (float)std::pow((double)alpha_f, (double)(std::abs(m) + std::abs(l)));
+    return ind;
+}
+
+// ---------------------------------------------------------------------------
+int CubicTablesDev::ensure(int srows, int scols, int drows, int dcols, hipStream_t st)
+{
+    if (srows == srows_ && scols == scols_ && drows == drows_ && dcols == dcols_)
+        return 0;
+    std::vector<int> sx, sy;
+    std::vector<float> al, be;
+    cubic_table_x(scols, dcols, sx, al);
+    cubic_table_y(srows, drows, sy, be);
+    // the previous tables may still be in use by queued kernels
+    SRX_HIP(hipStreamSynchronize(st));
+    if (int rc = xofs_.reserve(sx.size() * sizeof(int)))
+        return rc;
+    if (int rc = alpha_.reserve(al.size() * sizeof(float)))
+        return rc;
+    if (int rc = yofs_.reserve(sy.size() * sizeof(int)))
+        return rc;
+    if (int rc = beta_.reserve(be.size() * sizeof(float)))
+        return rc;
+    SRX_HIP(hipMemcpyAsync(xofs_.get(), sx.data(), sx.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    SRX_HIP(hipMemcpyAsync(alpha_.get(), al.data(), al.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    SRX_HIP(hipMemcpyAsync(yofs_.get(), sy.data(), sy.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    SRX_HIP(hipMemcpyAsync(beta_.get(), be.data(), be.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    SRX_HIP(hipStreamSynchronize(st)); // the host vectors go out of scope
+    srows_ = srows, scols_ = scols, drows_ = drows, dcols_ = dcols;
+    return 0;
+}
+
+CubicTables CubicTablesDev::view() const
+{
+    return CubicTables{xofs_.as<int>(), alpha_.as<float4>(), yofs_.as<int>(), beta_.as<float4>()};
+}
+
+// ---------------------------------------------------------------------------
+int Solver::ensure(int K, int rows, int cols, int ch, int scale, hipStream_t st)
+{
+    const size_t hr_px = (size_t)rows * scale * cols * scale;
+    if ((int)fwd_maps_.size() < K)
+    {
+        fwd_maps_.resize(K);
+        bwd_maps_.resize(K);
+        signs_.resize(K);
+        rel_.resize(K);
+    }
+    bool grow = x_[0].capacity() < hr_px * ch * sizeof(float);
+    for (int k = 0; k < K && !grow; ++k)
+        grow = fwd_maps_[k].capacity() < hr_px * 4 || signs_[k].capacity() < (size_t)rows * cols * 4 ||
+               rel_[k].capacity() < (size_t)rows * cols * 2 * sizeof(float);
+    if (grow)
+        SRX_HIP(hipStreamSynchronize(st)); // buffers about to be freed may still be in use
+    for (int k = 0; k < K; ++k)
+    {
+        if (int rc = fwd_maps_[k].reserve(hr_px * 4))
+            return rc;
+        if (int rc = bwd_maps_[k].reserve(hr_px * 4))
+            return rc;
+        if (int rc = signs_[k].reserve((size_t)rows * cols * 4))
+            return rc;
+        if (int rc = rel_[k].reserve((size_t)rows * cols * 2 * sizeof(float)))
+            return rc;
+    }
+    for (int i = 0; i < 2; ++i)
+        if (int rc = x_[i].reserve(hr_px * ch * sizeof(float)))
+            return rc;
+    return tables_.ensure(rows, cols, rows * scale, cols * scale, st);
+}
+
+void Solver::release()
+{
+    fwd_maps_.clear();
+    bwd_maps_.clear();
+    signs_.clear();
+    rel_.clear();
+    x_[0].release();
+    x_[1].release();
+    tables_ = CubicTablesDev();
+}
+
+int Solver::run(const float* const* y, const float* const* rel, int K, int base_idx, int rows, int cols, int ch,
+                const Params& p, float* out, float* x_full, hipStream_t st)
+{
+    if (int rc = validate_params(p))
+        return rc;
+    if (K < 1 || K > kMaxWindow || base_idx < 0 || base_idx >= K)
+    {
+        set_error("run: window size or base index out of range");
+        return SRX_ERR_INVALID;
+    }
+    if (ch != 1 && ch != 3)
+    {
+        set_error("run: frames must have 1 or 3 channels");
+        return SRX_ERR_INVALID;
+    }
+    const int s = p.scale, B = p.btvKernelSize;
+    const long R = (long)rows * s, C = (long)cols * s;
+    if (rows < 1 || cols < 1 || R > 32767 || C > 32767)
+    {
+        set_error("run: high-resolution size must be within 1..32767 per side");
+        return SRX_ERR_INVALID;
+    }
+    if (R - 2 * B < 1 || C - 2 * B < 1)
+    {
+        set_error("run: image smaller than the btvKernelSize crop");
+        return SRX_ERR_INVALID;
+    }
+    if (int rc = ensure(K, rows, cols, ch, s, st))
+        return rc;
+
+    // blur filter and btv weights are re-derived on parameter change (lib/src/btv_l1.cpp:392-405)
+    if (p.blurKernelSize != curBlurKernelSize_ || p.blurSigma != curBlurSigma_)
+    {
+        if (int rc = gaussian_kernel(p.blurKernelSize, p.blurSigma, gauss_.k))
+            return rc;
+        gauss_.n = p.blurKernelSize;
+        curBlurKernelSize_ = p.blurKernelSize;
+        curBlurSigma_ = p.blurSigma;
+    }
+    if (p.btvKernelSize != curBtvKernelSize_ || p.alpha != curAlpha_)
+    {
+        std::memset(btv_.w, 0, sizeof(btv_.w));
+        calc_btv_weights(p.btvKernelSize, p.alpha, btv_.w);
+        btv_.radius = (p.btvKernelSize - 1) / 2;
+        curBtvKernelSize_ = p.btvKernelSize;
+        curAlpha_ = p.alpha;
+    }
+
+    const CubicTables t = tables_.view();
+    PtrList fwd{}, bwd{}, ys{}, sg{};
+    MutPtrList sgm{};
+    for (int k = 0; k < K; ++k)
+    {
+        if (int rc = launch_build_maps(rel[k], rows, cols, s, t, fwd_maps_[k].as<int16_t>(),
+                                       bwd_maps_[k].as<int16_t>(), st))
+            return rc;
+        fwd.p[k] = fwd_maps_[k].get();
+        bwd.p[k] = bwd_maps_[k].get();
+        ys.p[k] = y[k];
+        sg.p[k] = signs_[k].get();
+        sgm.p[k] = signs_[k].get();
+    }
+
+    // initial estimation (lib/src/btv_l1.cpp:412)
+    cur_ = 0;
+    if (int rc = launch_resize_cubic(y[base_idx], rows, cols, ch, t, x_[0].as<float>(), (int)R, (int)C, st))
+        return rc;
+
+    for (int it = 0; it < p.iterations; ++it)
+    {
+        if (int rc = launch_forward_sign(x_[cur_].as<float>(), (int)R, (int)C, ch, bwd, ys, sgm, K, s, gauss_, st))
+            return rc;
+        if (int rc = launch_backproject_update(x_[cur_].as<float>(), x_[cur_ ^ 1].as<float>(), (int)R, (int)C, ch,
+                                               fwd, sg, K, s, gauss_, btv_, p.tau, p.lambda, st))
+            return rc;
+        cur_ ^= 1;
+    }
+
+    if (out)
+        if (int rc = launch_crop_convert(x_[cur_].as<float>(), (int)R, (int)C, ch, B, out, SRX_32F, st))
+            return rc;
+    if (x_full)
+        SRX_HIP(hipMemcpyAsync(x_full, x_[cur_].get(), (size_t)R * C * ch * sizeof(float), hipMemcpyDeviceToDevice,
+                               st));
+    return SRX_OK;
+}
+
+int Solver::process(const float* const* y, const float* const* fwd_motions, int K, int base_idx, int rows, int cols,
+                    int ch, const Params& p, float* out, float* x_full, hipStream_t st)
+{
+    if (K < 1 || K > kMaxWindow || base_idx < 0 || base_idx >= K)
+    {
+        set_error("process: window size or base index out of range");
+        return SRX_ERR_INVALID;
+    }
+    if (int rc = validate_params(p))
+        return rc;
+    if (int rc = ensure(K, rows, cols, ch, p.scale, st))
+        return rc;
+    PtrList f{};
+    MutPtrList r{};
+    const float* relp[kMaxWindow];
+    for (int k = 0; k < K; ++k)
+    {
+        if (k < K - 1)
+            f.p[k] = fwd_motions[k];
+        r.p[k] = rel_[k].get();
+        relp[k] = rel_[k].as<float>();
+    }
+    if (int rc = launch_relative_motions(f, r, K, base_idx, (size_t)rows * cols * 2, st))
+        return rc;
+    return run(y, relp, K, base_idx, rows, cols, ch, p, out, x_full, st);
+}
+
+} // namespace srx
