@@ -199,18 +199,25 @@ SRX_API int srx_k_btv_regularization(const float* src, int rows, int cols, int c
                                      const float* w_host, float* dst, void* stream);
 /* One window frame of the forward chain, lib/src/btv_l1.cpp:428-434:
  * sign(y - D H M X).  X: hr_rows x hr_cols x ch; bwd_map int16 pairs;
- * y: (hr_rows/scale) x (hr_cols/scale) x ch; sign_out: one int8x4 per LR
- * pixel (channels 0..ch-1 in bytes 0..ch-1). */
+ * y: (hr_rows/scale) x (hr_cols/scale) x ch; sign_out: one uint32 per LR
+ * pixel holding sign+1 (0, 1 or 2) of channel c in bits 10c..10c+1. */
 SRX_API int srx_k_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const int16_t* bwd_map,
-                               const float* y, int scale, const float* gauss_host, int gauss_n, int8_t* sign_out,
+                               const float* y, int scale, const float* gauss_host, int gauss_n, uint32_t* sign_out,
                                void* stream);
 /* The transposed chain for K frames plus regulariser and update,
  * lib/src/btv_l1.cpp:437-452: X_out = X + tau * (sum_k M^T H^T D^T sign_k - lambda * btv(X)).
- * fwd_maps_host / signs_host: host arrays of K device pointers. */
+ * fwd_maps_host / signs_host: host arrays of K device pointers (sign planes
+ * in the encoding of srx_k_forward_sign). */
 SRX_API int srx_k_backproject_update(const float* X, float* X_out, int hr_rows, int hr_cols, int ch,
-                                     const int16_t* const* fwd_maps_host, const int8_t* const* signs_host, int K,
+                                     const int16_t* const* fwd_maps_host, const uint32_t* const* signs_host, int K,
                                      int scale, const float* gauss_host, int gauss_n, int btv_kernel_size,
                                      const float* w_host, double tau, double lambda, void* stream);
+/* Diagnostic switch, process-wide: 0 (default) lets the solver and the two
+ * entry points above use the kernels specialised for scale 4 / 5-tap blur /
+ * btvKernelSize 7 whenever the parameters allow; 1 forces the generic kernels.
+ * Both compute the same values. */
+SRX_API int srx_set_kernel_path(int path);
+SRX_API int srx_get_kernel_path(void);
 /* Rect inner(B,B,..) crop of lib/src/btv_l1.cpp:455-456 and, for depth
  * SRX_8U, Mat::convertTo(CV_8U) (lib/src/btv_l1.cpp:504). */
 SRX_API int srx_k_crop_convert(const float* X, int rows, int cols, int ch, int border, void* dst, int depth,

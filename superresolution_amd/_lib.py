@@ -80,6 +80,8 @@ SIGNATURES = {
     "srx_k_crop_convert": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp]),
     "srx_run": (C.c_int, [_vp, _vpp, _vpp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "srx_process_device": (C.c_int, [_vp, _vpp, _vpp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "srx_set_kernel_path": (C.c_int, [C.c_int]),
+    "srx_get_kernel_path": (C.c_int, []),
     "srx_stream": (_vp, [_vp]),
     "srx_synchronize": (C.c_int, [_vp]),
 }

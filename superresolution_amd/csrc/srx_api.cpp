@@ -971,7 +971,7 @@ SRX_API int srx_k_build_maps(const float* rel, int rows, int cols, int scale, in
     CubicTablesDev t;
     if (int rc = t.ensure(rows, cols, rows * scale, cols * scale, (hipStream_t)stream))
         return rc;
-    if (int rc = launch_build_maps(rel, rows, cols, scale, t.view(), fwd_map, bwd_map, (hipStream_t)stream))
+    if (int rc = launch_build_maps(rel, rows, cols, scale, t.view(), fwd_map, bwd_map, nullptr, nullptr, (hipStream_t)stream))
         return rc;
     SRX_HIP(hipStreamSynchronize((hipStream_t)stream)); // the tables die with this call
     return SRX_OK;
@@ -1039,52 +1039,117 @@ SRX_API int srx_k_btv_regularization(const float* src, int rows, int cols, int c
 }
 
 SRX_API int srx_k_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const int16_t* bwd_map,
-                               const float* y, int scale, const float* gauss_host, int gauss_n, int8_t* sign_out,
+                               const float* y, int scale, const float* gauss_host, int gauss_n, uint32_t* sign_out,
                                void* stream)
 {
     if (!X || !bwd_map || !y || !sign_out || scale < 2 || hr_rows < scale || hr_cols < scale ||
-        hr_rows % scale || hr_cols % scale || hr_rows > 32767 || hr_cols > 32767)
+        hr_rows % scale || hr_cols % scale || hr_rows > 32767 || hr_cols > 32767 || (ch != 1 && ch != 3))
     {
         set_error("srx_k_forward_sign: bad arguments");
         return SRX_ERR_INVALID;
     }
+    hipStream_t st = (hipStream_t)stream;
     GaussK g;
     if (int rc = make_gauss(gauss_host, gauss_n, g))
         return rc;
-    PtrList maps{}, ys{};
+    PtrList maps{}, ys{}, dmaps{};
     MutPtrList sg{};
     maps.p[0] = bwd_map;
     ys.p[0] = y;
     sg.p[0] = sign_out;
-    return launch_forward_sign(X, hr_rows, hr_cols, ch, maps, ys, sg, 1, scale, g, (hipStream_t)stream);
+    if (g_kernel_path == 0 && forward_fast_eligible(hr_rows, hr_cols, ch, scale, g))
+    {
+        // the specialised kernel wants a decoded map and an X with a trailing zero pixel
+        const size_t px = (size_t)hr_rows * hr_cols;
+        DeviceBuffer xpad, dec;
+        if (int rc = xpad.reserve((px + 1) * ch * sizeof(float)))
+            return rc;
+        if (int rc = dec.reserve(px * 4))
+            return rc;
+        SRX_HIP(hipMemcpyAsync(xpad.get(), X, px * ch * sizeof(float), hipMemcpyDeviceToDevice, st));
+        SRX_HIP(hipMemsetAsync(xpad.as<float>() + px * ch, 0, ch * sizeof(float), st));
+        if (int rc = launch_decode_maps(nullptr, bwd_map, hr_rows, hr_cols, nullptr, dec.as<uint32_t>(), st))
+            return rc;
+        dmaps.p[0] = dec.get();
+        if (int rc = launch_forward_sign(xpad.as<float>(), hr_rows, hr_cols, ch, maps, &dmaps, ys, sg, 1, scale, g,
+                                         st))
+            return rc;
+        SRX_HIP(hipStreamSynchronize(st)); // the temporaries die with this call
+        return SRX_OK;
+    }
+    return launch_forward_sign(X, hr_rows, hr_cols, ch, maps, nullptr, ys, sg, 1, scale, g, st);
 }
 
 SRX_API int srx_k_backproject_update(const float* X, float* X_out, int hr_rows, int hr_cols, int ch,
-                                     const int16_t* const* fwd_maps_host, const int8_t* const* signs_host, int K,
+                                     const int16_t* const* fwd_maps_host, const uint32_t* const* signs_host, int K,
                                      int scale, const float* gauss_host, int gauss_n, int btv_kernel_size,
                                      const float* w_host, double tau, double lambda, void* stream)
 {
     if (!X || !X_out || X == X_out || !fwd_maps_host || !signs_host || K < 0 || K > kMaxWindow || scale < 2 ||
         hr_rows % scale || hr_cols % scale || hr_rows < scale || hr_cols < scale || hr_rows > 32767 ||
-        hr_cols > 32767)
+        hr_cols > 32767 || (ch != 1 && ch != 3))
     {
         set_error("srx_k_backproject_update: bad arguments");
         return SRX_ERR_INVALID;
     }
+    hipStream_t st = (hipStream_t)stream;
     GaussK g;
     if (int rc = make_gauss(gauss_host, gauss_n, g))
         return rc;
     BtvW bw;
     if (int rc = make_btv(btv_kernel_size, w_host, bw))
         return rc;
-    PtrList maps{}, sg{};
+    PtrList maps{}, sg{}, dmaps{};
     for (int k = 0; k < K; ++k)
     {
         maps.p[k] = fwd_maps_host[k];
         sg.p[k] = signs_host[k];
     }
-    return launch_backproject_update(X, X_out, hr_rows, hr_cols, ch, maps, sg, K, scale, g, bw, tau, lambda,
-                                     (hipStream_t)stream);
+    if (g_kernel_path == 0 && backproject_fast_eligible(hr_rows, hr_cols, ch, scale, g, bw))
+    {
+        // the specialised kernel wants decoded maps and sign planes padded by one row and one word
+        const size_t px = (size_t)hr_rows * hr_cols;
+        const size_t lr = (size_t)(hr_rows / 4) * (hr_cols / 4);
+        const size_t padded = ((size_t)(hr_rows / 4 + 1) * (hr_cols / 4) + 1) * 4;
+        std::vector<DeviceBuffer> dec(K), spad(K);
+        for (int k = 0; k < K; ++k)
+        {
+            if (int rc = dec[k].reserve(px * 4))
+                return rc;
+            if (int rc = spad[k].reserve(padded))
+                return rc;
+            SRX_HIP(hipMemsetAsync(spad[k].get(), 0, padded, st));
+            SRX_HIP(hipMemcpyAsync(spad[k].get(), signs_host[k], lr * 4, hipMemcpyDeviceToDevice, st));
+            if (int rc = launch_decode_maps(fwd_maps_host[k], nullptr, hr_rows, hr_cols, dec[k].as<uint32_t>(),
+                                            nullptr, st))
+                return rc;
+            dmaps.p[k] = dec[k].get();
+            sg.p[k] = spad[k].get();
+        }
+        if (int rc = launch_backproject_update(X, X_out, hr_rows, hr_cols, ch, maps, &dmaps, sg, K, scale, g, bw, tau,
+                                               lambda, st))
+            return rc;
+        SRX_HIP(hipStreamSynchronize(st));
+        return SRX_OK;
+    }
+    return launch_backproject_update(X, X_out, hr_rows, hr_cols, ch, maps, nullptr, sg, K, scale, g, bw, tau, lambda,
+                                     st);
+}
+
+SRX_API int srx_set_kernel_path(int path)
+{
+    if (path != 0 && path != 1)
+    {
+        set_error("kernel path must be 0 (auto) or 1 (generic)");
+        return SRX_ERR_INVALID;
+    }
+    g_kernel_path = path;
+    return SRX_OK;
+}
+
+SRX_API int srx_get_kernel_path(void)
+{
+    return g_kernel_path;
 }
 
 SRX_API int srx_k_crop_convert(const float* X, int rows, int cols, int ch, int border, void* dst, int depth,

@@ -58,17 +58,28 @@ int hip_fail(hipError_t e, const char* what);
 // ---- launchers (srx_kernels.hip) -----------------------------------------
 int launch_relative_motions(const PtrList& fwd, const MutPtrList& rel, int n, int base_idx, size_t count,
                             hipStream_t st);
+// dec_fwd / dec_bwd (optional, scale 4 only): decoded maps for the specialised kernels
 int launch_build_maps(const float* rel, int rows, int cols, int scale, const CubicTables& t, int16_t* fwd_map,
-                      int16_t* bwd_map, hipStream_t st);
+                      int16_t* bwd_map, uint32_t* dec_fwd, uint32_t* dec_bwd, hipStream_t st);
+int launch_decode_maps(const int16_t* fwd_map, const int16_t* bwd_map, int hr_rows, int hr_cols, uint32_t* dec_fwd,
+                       uint32_t* dec_bwd, hipStream_t st);
 int launch_resize_cubic(const float* src, int srows, int scols, int ch, const CubicTables& t, float* dst, int drows,
                         int dcols, hipStream_t st);
 int launch_btv_regularization(const float* src, int rows, int cols, int ch, const BtvW& w, float* dst, hipStream_t st);
-// sign(y_k - D H M_k X) for K frames in one launch
-int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const PtrList& bwd_maps, const PtrList& y,
-                        const MutPtrList& signs, int K, int scale, const GaussK& g, hipStream_t st);
-int launch_backproject_update(const float* X, float* X_out, int hr_rows, int hr_cols, int ch, const PtrList& fwd_maps,
-                              const PtrList& signs, int K, int scale, const GaussK& g, const BtvW& w, double tau,
-                              double lambda, hipStream_t st);
+// Which parameter sets the specialised kernels cover.
+bool forward_fast_eligible(int hr_rows, int hr_cols, int ch, int scale, const GaussK& g);
+bool backproject_fast_eligible(int hr_rows, int hr_cols, int ch, int scale, const GaussK& g, const BtvW& w);
+// sign(y_k - D H M_k X) for K frames in one launch.  With dec_bwd (and an
+// eligible parameter set) the specialised kernel runs; it needs X to carry the
+// zero pixel at index hr_rows*hr_cols.
+int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const PtrList& raw_bwd,
+                        const PtrList* dec_bwd, const PtrList& y, const MutPtrList& signs, int K, int scale,
+                        const GaussK& g, hipStream_t st);
+// With dec_fwd (and an eligible parameter set) the specialised kernel runs; it
+// needs every sign buffer to hold (rows/4 + 1) * (cols/4) + 1 words.
+int launch_backproject_update(const float* X, float* X_out, int hr_rows, int hr_cols, int ch, const PtrList& raw_fwd,
+                              const PtrList* dec_fwd, const PtrList& signs, int K, int scale, const GaussK& g,
+                              const BtvW& w, double tau, double lambda, hipStream_t st);
 int launch_crop_convert(const float* X, int rows, int cols, int ch, int border, void* dst, int depth, hipStream_t st);
 int launch_convert_8u_to_32f(const uint8_t* src, size_t count, float* dst, hipStream_t st);
 

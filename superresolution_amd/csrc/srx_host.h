@@ -75,6 +75,9 @@ struct Params
 
 const std::string& last_error();
 
+// 0: specialised kernels wherever the parameters allow (default); 1: generic kernels only
+extern int g_kernel_path;
+
 // Validates what the reference only debug-asserts (lib/src/btv_l1.cpp:359-365).
 int validate_params(const Params& p);
 
@@ -110,7 +113,7 @@ class Solver
 
   private:
     int ensure(int K, int rows, int cols, int ch, int scale, hipStream_t st);
-    std::vector<DeviceBuffer> fwd_maps_, bwd_maps_, signs_, rel_;
+    std::vector<DeviceBuffer> fwd_maps_, bwd_maps_, dec_fwd_, dec_bwd_, signs_, rel_;
     DeviceBuffer x_[2];
     int cur_ = 0;
     CubicTablesDev tables_;

@@ -1,14 +1,25 @@
 // HIP kernels of the BTV-L1 solver for gfx950 (MI355X).
 //
 // Build with -ffp-contract=off: the solver's sign() steps make the iteration
-// sensitive to the last bit, so every float operation below is meant to round
-// exactly as written (same order as the OpenCV routines the reference calls).
+// sensitive to the last bit, so every float operation below rounds exactly as
+// written, in the order of the OpenCV routines the reference calls.
 //
 // Data layout in HBM
-//   images      float32, channels interleaved, dense rows
-//   index maps  int16 (x, y) per HR pixel: the source index cv::remap(INTER_NEAREST)
-//               derives from the float map (round half to even, saturate)
-//   signs       one int8x4 per LR pixel and window frame (bytes 0..ch-1 used)
+//   images        float32, channels interleaved, dense rows.  Solver-owned HR
+//                 images carry one extra all-zero pixel at index rows*cols
+//                 (the value of cv::remap's constant border).
+//   raw maps      int16 (x, y) per HR pixel: the source index that
+//                 cv::remap(INTER_NEAREST) derives from its float map.
+//   decoded maps  one uint32 per HR pixel, derived from the raw maps for the
+//                 specialised kernels:
+//                   backward: linear source pixel index, or rows*cols (the
+//                             zero pixel) when the source is outside;
+//                   forward:  see kFwd* below.
+//   signs         one uint32 per LR pixel and window frame: sign+1 (0,1,2) of
+//                 channel c in bits 10c..10c+1.
+//
+// Two families of kernels compute the same values: generic ones (any scale,
+// blur size, BTV size) and specialised ones (scale 4, 5-tap blur, BTV 7).
 #include "srx_common.h"
 
 namespace srx
@@ -16,6 +27,13 @@ namespace srx
 
 namespace
 {
+
+// forward decoded-map entry (scale 4, 5-tap blur): a target (fx, fy) touches at
+// most the 2x2 block of LR sign cells whose top-left cell is `cell`
+constexpr uint32_t kFwdCellMask = 0x00FFFFFFu; // bits 0..23  cell index (row*w + col)
+constexpr int kFwdPhaseShift = 24;             // bits 24..25 fx & 3, bits 26..27 fy & 3
+constexpr uint32_t kFwdSlow = 0x40000000u;     // target within 2 px of the image edge: reflect101 in play
+constexpr uint32_t kFwdOutside = 0x80000000u;  // target outside the image: contributes 0
 
 __device__ __forceinline__ int reflect101(int p, int len)
 {
@@ -49,6 +67,17 @@ __device__ __forceinline__ short round_sat16(float v)
     float r = rintf(v);
     r = fminf(fmaxf(r, -32768.0f), 32767.0f);
     return (short)(int)r;
+}
+
+// Blocks are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).
+// Give each XCD one contiguous range of the work list so that neighbouring
+// work items (which share halos and gather targets) meet in one L2.
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned b, unsigned n)
+{
+    const unsigned xcd = b & 7u, local = b >> 3;
+    const unsigned q = n >> 3, r = n & 7u;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + local;
 }
 
 // ---------------------------------------------------------------------------
@@ -96,10 +125,28 @@ __device__ __forceinline__ void cubic_sample(const float* __restrict__ src, int 
         out[c] = h[0][c] * b.x + h[1][c] * b.y + h[2][c] * b.z + h[3][c] * b.w;
 }
 
+// decoded map entries (layout at the top of this file); w = C / 4 LR columns
+__device__ __forceinline__ uint32_t decode_bwd(int bx, int by, int R, int C)
+{
+    return ((unsigned)bx < (unsigned)C && (unsigned)by < (unsigned)R) ? (uint32_t)(by * C + bx) : (uint32_t)(R * C);
+}
+__device__ __forceinline__ uint32_t decode_fwd(int fx, int fy, int R, int C)
+{
+    if ((unsigned)fx >= (unsigned)C || (unsigned)fy >= (unsigned)R)
+        return kFwdOutside;
+    if (fx < 2 || fx > C - 3 || fy < 2 || fy > R - 3)
+        return kFwdSlow;
+    const int px = fx & 3, py = fy & 3;
+    const int col = (fx >> 2) + (px == 3), row = (fy >> 2) + (py == 3);
+    return (uint32_t)(row * (C >> 2) + col) | ((uint32_t)(px | (py << 2)) << kFwdPhaseShift);
+}
+
 // upscaleMotions + buildMotionMaps + remap's float->short index conversion
-// (lib/src/btv_l1.cpp:59-101; cv::remap INTER_NEAREST)
+// (lib/src/btv_l1.cpp:59-101; cv::remap INTER_NEAREST), plus the decoded maps
+// for the specialised kernels when dec_fwd / dec_bwd are given (scale 4 only).
 __global__ void k_build_maps(const float* __restrict__ rel, int rows, int cols, int scale, CubicTables t,
-                             short2* __restrict__ fwd_map, short2* __restrict__ bwd_map)
+                             short2* __restrict__ fwd_map, short2* __restrict__ bwd_map, uint32_t* __restrict__ dec_fwd,
+                             uint32_t* __restrict__ dec_bwd)
 {
     const int R = rows * scale, C = cols * scale;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -110,11 +157,30 @@ __global__ void k_build_maps(const float* __restrict__ rel, int rows, int cols, 
     cubic_sample<2>(rel, rows, cols, t.xofs[x], t.alpha[x], t.yofs[y], t.beta[y], m);
     const float s = (float)scale;
     const float mx = m[0] * s, my = m[1] * s;
-    const float fx = (float)x - mx, fy = (float)y - my;
-    const float bx = (float)x + mx, by = (float)y + my;
+    const int fx = round_sat16((float)x - mx), fy = round_sat16((float)y - my);
+    const int bx = round_sat16((float)x + mx), by = round_sat16((float)y + my);
     const size_t o = (size_t)y * C + x;
-    fwd_map[o] = make_short2(round_sat16(fx), round_sat16(fy));
-    bwd_map[o] = make_short2(round_sat16(bx), round_sat16(by));
+    fwd_map[o] = make_short2((short)fx, (short)fy);
+    bwd_map[o] = make_short2((short)bx, (short)by);
+    if (dec_bwd)
+        dec_bwd[o] = decode_bwd(bx, by, R, C);
+    if (dec_fwd)
+        dec_fwd[o] = decode_fwd(fx, fy, R, C);
+}
+
+// raw int16 maps -> decoded maps (same rules as k_build_maps), for callers that hold raw maps only
+__global__ void k_decode_maps(const short2* __restrict__ fwd_map, const short2* __restrict__ bwd_map, int R, int C,
+                              uint32_t* __restrict__ dec_fwd, uint32_t* __restrict__ dec_bwd)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= C || y >= R)
+        return;
+    const size_t o = (size_t)y * C + x;
+    if (dec_bwd)
+        dec_bwd[o] = decode_bwd(bwd_map[o].x, bwd_map[o].y, R, C);
+    if (dec_fwd)
+        dec_fwd[o] = decode_fwd(fwd_map[o].x, fwd_map[o].y, R, C);
 }
 
 template <int CH>
@@ -133,7 +199,10 @@ __global__ void k_resize_cubic(const float* __restrict__ src, int srows, int sco
         D[c] = v[c];
 }
 
-// ---------------------------------------------------------------------------
+// ===========================================================================
+// Generic kernels
+// ===========================================================================
+
 // BTV regulariser at one pixel (lib/src/btv_l1.cpp:212-235), straight from
 // global memory.  Border band of width `radius` stays zero.
 template <int CH>
@@ -179,8 +248,6 @@ __global__ void k_btv_regularization(const float* __restrict__ X, int H, int W, 
         D[c] = reg[c];
 }
 
-// ---------------------------------------------------------------------------
-// Forward chain, generic in scale and blur size.
 // a(Y, X) = Xhr(bwd(Y, X)) or 0 outside   (remap NEAREST, constant border)
 template <int CH>
 __device__ __forceinline__ void fetch_warped(const float* __restrict__ X, int H, int W,
@@ -242,19 +309,14 @@ __device__ __forceinline__ void warped_blur_row(const float* __restrict__ X, int
     }
 }
 
-// sign(y_k - D H M_k X) for every LR pixel and window frame (blockIdx.z = k)
-// lib/src/btv_l1.cpp:428-434
+// sign(y - D H M X) at one LR pixel, any scale / blur size (lib/src/btv_l1.cpp:428-434)
 template <int CH>
-__global__ void k_forward_sign(const float* __restrict__ X, int H, int W, PtrList bwd_maps, PtrList ys,
-                               MutPtrList signs, int scale, GaussK g)
+__device__ __forceinline__ uint32_t forward_sign_generic(const float* __restrict__ X, int H, int W,
+                                                         const short2* __restrict__ map,
+                                                         const float* __restrict__ yk, int x, int y, int scale,
+                                                         const GaussK& g)
 {
-    const int h = H / scale, w = W / scale;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    const int k = blockIdx.z;
-    if (x >= w || y >= h)
-        return;
-    const short2* map = (const short2*)bwd_maps.p[k];
+    const int w = W / scale;
     const int Yc = y * scale, Xc = x * scale;
     const int hh = g.n >> 1;
     float acc[CH], ra[CH], rb[CH];
@@ -271,34 +333,42 @@ __global__ void k_forward_sign(const float* __restrict__ X, int H, int W, PtrLis
         for (int c = 0; c < CH; ++c)
             acc[c] += (ra[c] + rb[c]) * g.k[hh + j];
     }
-    const float* yk = (const float*)ys.p[k] + ((size_t)y * w + x) * CH;
-    char4 s = make_char4(0, 0, 0, 0);
-    signed char sv[4] = {0, 0, 0, 0};
+    const float* yp = yk + ((size_t)y * w + x) * CH;
+    uint32_t s = 0;
 #pragma unroll
     for (int c = 0; c < CH; ++c)
-        sv[c] = (signed char)dsign(yk[c], acc[c]);
-    s.x = sv[0];
-    s.y = sv[1];
-    s.z = sv[2];
-    s.w = sv[3];
-    ((char4*)signs.p[k])[(size_t)y * w + x] = s;
+        s |= (uint32_t)((int)dsign(yp[c], acc[c]) + 1) << (10 * c);
+    return s;
 }
 
-// ---------------------------------------------------------------------------
-// Transposed chain, generic.  B(fy, fx) = gauss(zero_insert(sign))(fy, fx)
-// evaluated lazily: the zero-inserted image is non-zero only where both
-// coordinates are multiples of scale.
 template <int CH>
-__device__ __forceinline__ void sign_at(const char4* __restrict__ sg, int w, int scale, int Yr, int Xr, float (&o)[CH])
+__global__ void k_forward_sign(const float* __restrict__ X, int H, int W, PtrList bwd_maps, PtrList ys,
+                               MutPtrList signs, int scale, GaussK g)
+{
+    const int h = H / scale, w = W / scale;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = blockIdx.z;
+    if (x >= w || y >= h)
+        return;
+    ((uint32_t*)signs.p[k])[(size_t)y * w + x] =
+        forward_sign_generic<CH>(X, H, W, (const short2*)bwd_maps.p[k], (const float*)ys.p[k], x, y, scale, g);
+}
+
+// Transposed chain.  B(fy, fx) = gauss(zero_insert(sign))(fy, fx) evaluated
+// lazily: the zero-inserted image is non-zero only where both coordinates are
+// multiples of scale.
+template <int CH>
+__device__ __forceinline__ void sign_at(const uint32_t* __restrict__ sg, int w, int scale, int Yr, int Xr,
+                                        float (&o)[CH])
 {
     // caller guarantees Yr % scale == 0
     if (Xr % scale == 0)
     {
-        const char4 s = sg[(size_t)(Yr / scale) * w + (Xr / scale)];
-        const float sv[4] = {(float)s.x, (float)s.y, (float)s.z, (float)s.w};
+        const uint32_t s = sg[(size_t)(Yr / scale) * w + (Xr / scale)];
 #pragma unroll
         for (int c = 0; c < CH; ++c)
-            o[c] = sv[c];
+            o[c] = (float)((int)((s >> (10 * c)) & 3u) - 1);
     }
     else
     {
@@ -309,7 +379,7 @@ __device__ __forceinline__ void sign_at(const char4* __restrict__ sg, int w, int
 }
 
 template <int CH>
-__device__ __forceinline__ void upsampled_blur_row(const char4* __restrict__ sg, int W, int scale, int Yr, int fx,
+__device__ __forceinline__ void upsampled_blur_row(const uint32_t* __restrict__ sg, int W, int scale, int Yr, int fx,
                                                    const GaussK& g, float (&r)[CH])
 {
     if (Yr % scale != 0)
@@ -353,6 +423,27 @@ __device__ __forceinline__ void upsampled_blur_row(const char4* __restrict__ sg,
     }
 }
 
+// (M^T H^T D^T sign)(i, j) for one frame: gather at the forward-map target
+template <int CH>
+__device__ __forceinline__ void backproject_generic(const uint32_t* __restrict__ sg, int H, int W, int scale, int fx,
+                                                    int fy, const GaussK& g, float (&a)[CH])
+{
+    const int hh = g.n >> 1;
+    float ra[CH], rb[CH];
+    upsampled_blur_row<CH>(sg, W, scale, fy, fx, g, ra);
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+        a[c] = ra[c] * g.k[hh];
+    for (int t = 1; t <= hh; ++t)
+    {
+        upsampled_blur_row<CH>(sg, W, scale, reflect101(fy - t, H), fx, g, ra);
+        upsampled_blur_row<CH>(sg, W, scale, reflect101(fy + t, H), fx, g, rb);
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            a[c] += (ra[c] + rb[c]) * g.k[hh + t];
+    }
+}
+
 // X_out = X + tau * (sum_k M_k^T H^T D^T sign_k - lambda * btv(X))
 // lib/src/btv_l1.cpp:437-452; both addWeighted steps evaluate in double.
 template <int CH>
@@ -364,7 +455,6 @@ __global__ void k_backproject_update(const float* __restrict__ X, float* __restr
     const int i = blockIdx.y * blockDim.y + threadIdx.y;
     if (j >= W || i >= H)
         return;
-    const int hh = g.n >> 1;
     float diff[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c)
@@ -375,20 +465,8 @@ __global__ void k_backproject_update(const float* __restrict__ X, float* __restr
         const int fx = m.x, fy = m.y;
         if ((unsigned)fx >= (unsigned)W || (unsigned)fy >= (unsigned)H)
             continue; // remap border: constant 0
-        const char4* sg = (const char4*)signs.p[k];
-        float a[CH], ra[CH], rb[CH];
-        upsampled_blur_row<CH>(sg, W, scale, fy, fx, g, ra);
-#pragma unroll
-        for (int c = 0; c < CH; ++c)
-            a[c] = ra[c] * g.k[hh];
-        for (int t = 1; t <= hh; ++t)
-        {
-            upsampled_blur_row<CH>(sg, W, scale, reflect101(fy - t, H), fx, g, ra);
-            upsampled_blur_row<CH>(sg, W, scale, reflect101(fy + t, H), fx, g, rb);
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-                a[c] += (ra[c] + rb[c]) * g.k[hh + t];
-        }
+        float a[CH];
+        backproject_generic<CH>((const uint32_t*)signs.p[k], H, W, scale, fx, fy, g, a);
 #pragma unroll
         for (int c = 0; c < CH; ++c)
             diff[c] = diff[c] + a[c];
@@ -406,6 +484,291 @@ __global__ void k_backproject_update(const float* __restrict__ X, float* __restr
 #pragma unroll
     for (int c = 0; c < CH; ++c)
         D[c] = (float)((double)P[c] + (double)diff[c] * tau);
+}
+
+// ===========================================================================
+// Specialised kernels: scale 4, 5-tap blur (and BTV kernel size 7 for the update)
+// ===========================================================================
+
+// Forward chain for one 64x4 tile of LR pixels and one window frame per block.
+// Work list = (tile, k) with k fastest, split into one contiguous range per XCD
+// so that the K gathers over a tile of X run back to back against one L2.
+// Per LR pixel: 5 rows x 5 taps; map entries come as one 8-byte and one 16-byte
+// load per row, X pixels as one CH-float gather per tap.
+template <int CH>
+__global__ __launch_bounds__(256) void k_forward_sign_s4(const float* __restrict__ X, int H, int W, PtrList dec_bwd,
+                                                          PtrList raw_bwd, PtrList ys, MutPtrList signs, int K,
+                                                          GaussK g, int tiles_x, unsigned n_items)
+{
+    const unsigned item = xcd_contiguous(blockIdx.x, n_items);
+    if (item >= n_items)
+        return;
+    const int k = item % K;
+    const unsigned tile = item / K;
+    const int h = H >> 2, w = W >> 2;
+    const int x = (tile % tiles_x) * 64 + (threadIdx.x & 63);
+    const int y = (tile / tiles_x) * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h)
+        return;
+    uint32_t* out = (uint32_t*)signs.p[k] + (size_t)y * w + x;
+    if (x == 0 || y == 0)
+    {
+        // taps reach over the left/top edge: reflect101 path
+        *out = forward_sign_generic<CH>(X, H, W, (const short2*)raw_bwd.p[k], (const float*)ys.p[k], x, y, 4, g);
+        return;
+    }
+    const uint32_t* map = (const uint32_t*)dec_bwd.p[k] + (size_t)(4 * y - 2) * W + (4 * x - 2);
+    const float k0 = g.k[2], k1 = g.k[3], k2 = g.k[4];
+    float rr[5][CH];
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+    {
+        const uint32_t* mr = map + (size_t)r * W;
+        const uint2 ma = *(const uint2*)mr;       // columns 4x-2, 4x-1
+        const uint4 mb = *(const uint4*)(mr + 2); // columns 4x .. 4x+3
+        const float* pm2 = X + (size_t)ma.x * CH;
+        const float* pm1 = X + (size_t)ma.y * CH;
+        const float* pc = X + (size_t)mb.x * CH;
+        const float* pp1 = X + (size_t)mb.y * CH;
+        const float* pp2 = X + (size_t)mb.z * CH;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+        {
+            float s = pc[c] * k0;
+            s += (pm1[c] + pp1[c]) * k1;
+            s += (pm2[c] + pp2[c]) * k2;
+            rr[r][c] = s;
+        }
+    }
+    const float* yp = (const float*)ys.p[k] + ((size_t)y * w + x) * CH;
+    uint32_t sg = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+    {
+        float s = rr[2][c] * k0;
+        s += (rr[1][c] + rr[3][c]) * k1;
+        s += (rr[0][c] + rr[4][c]) * k2;
+        sg |= (uint32_t)((int)dsign(yp[c], s) + 1) << (10 * c);
+    }
+    *out = sg;
+}
+
+// Integer weights of the transposed 5-tap blur for dyadic kernels (k*16 integer):
+// per phase pair (fx&3, fy&3) the weights of the 2x2 block of sign cells, in
+// units of 1/256, and their sum.
+struct FastW
+{
+    uint32_t w[16][4]; // [px | py << 2][AA, AB, BA, BB]
+    uint32_t wsum[16];
+};
+
+// order-preserving float <-> int key (an involution); -0 is folded into +0 so
+// that integer order equals float order for all non-NaN values
+__device__ __forceinline__ int float_key(float x)
+{
+    const int b = __float_as_int(x + 0.0f);
+    return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float key_float(int k)
+{
+    return __int_as_float(k ^ ((k >> 31) & 0x7fffffff));
+}
+// sign(a - b) for keys: saturating subtract, then clamp to [-1, 1]
+__device__ __forceinline__ int key_sign(int a, int b)
+{
+    int d, s;
+    asm("v_sub_i32 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
+    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(s) : "v"(d));
+    return s;
+}
+
+// Back-projection of all K frames + BTV regulariser + update for one 64x16 tile
+// of HR pixels per block; each thread owns 4 consecutive pixels of one row.
+//  * per frame: one 16-byte load of 4 decoded forward-map entries, then per pixel
+//    the 2x2 block of sign cells times the phase's integer weights (exact for
+//    dyadic blur kernels: every partial sum is a multiple of 1/256)
+//  * BTV: the tile of X (+3 px halo) sits in LDS as order-preserving integer
+//    keys; sign(a-b) is a saturating subtract and a clamp; accumulation order is
+//    the reference's (lib/src/btv_l1.cpp:221-233).  NaN pixels are ordered as
+//    large values instead of comparing unordered.
+template <int CH>
+__global__ __launch_bounds__(256) void k_backproject_update_s4(const float* __restrict__ X, float* __restrict__ X_out,
+                                                                int H, int W, PtrList dec_fwd, PtrList raw_fwd,
+                                                                PtrList signs, int K, GaussK g, FastW fw, BtvW bw,
+                                                                double tau, double lambda, int tiles_x,
+                                                                unsigned n_tiles)
+{
+    constexpr int TXN = 16, TYN = 16, PXT = 4;
+    constexpr int TW = TXN * PXT;       // 64 px
+    constexpr int HALO = 3, HL = 4;     // halo; left halo padded to 4 px so that row loads are 16-byte aligned
+    constexpr int LW = TW + HL + 4;     // 72 px held per LDS row: [j0-4, j0+68)
+    constexpr int LROWS = TYN + 2 * HALO;
+    constexpr int PITCH = CH == 3 ? 256 : 128; // floats; a multiple of 64 keeps ds_read_b128 conflict-free
+    constexpr int NV = CH == 3 ? 9 : 3;        // 16-byte LDS reads per window row
+    constexpr int OFF = CH == 3 ? 3 : 1;       // first needed float within the aligned window
+    constexpr int NE = PXT * CH;               // outputs per thread
+    __shared__ __attribute__((aligned(16))) int tile[LROWS * PITCH];
+    __shared__ uint4 lutw[16];
+    __shared__ uint32_t luts[16];
+
+    const unsigned t = xcd_contiguous(blockIdx.x, n_tiles);
+    if (t >= n_tiles)
+        return;
+    const int j0 = (t % tiles_x) * TW, i0 = (t / tiles_x) * TYN;
+    const int tid = threadIdx.x;
+    const int tx = tid & (TXN - 1), ty = tid >> 4;
+    const int w = W >> 2;
+
+    if (tid < 16)
+    {
+        lutw[tid] = make_uint4(fw.w[tid][0], fw.w[tid][1], fw.w[tid][2], fw.w[tid][3]);
+        luts[tid] = fw.wsum[tid];
+    }
+    // ---- stage the X tile (as keys) in LDS
+    {
+        constexpr int V4 = LW * CH / 4; // float4 per row: 54 or 18
+        const int rowf = W * CH;
+        for (int idx = tid; idx < LROWS * V4; idx += 256)
+        {
+            const int r = idx / V4, c4 = idx - r * V4;
+            const int gi = i0 - HALO + r;
+            const int f0 = (j0 - HL) * CH + 4 * c4;
+            int4 kv = make_int4(0, 0, 0, 0);
+            if (gi >= 0 && gi < H && f0 >= 0 && f0 + 3 < rowf)
+            {
+                const float4 v = *(const float4*)(X + (size_t)gi * rowf + f0);
+                kv = make_int4(float_key(v.x), float_key(v.y), float_key(v.z), float_key(v.w));
+            }
+            *(int4*)&tile[r * PITCH + 4 * c4] = kv;
+        }
+    }
+    __syncthreads();
+
+    const int i = i0 + ty, j = j0 + tx * PXT;
+    if (i >= H || j >= W)
+        return; // W is a multiple of 4: a thread's 4 pixels are all inside or all outside
+
+    // ---- sum over frames of M^T H^T D^T sign, in units of 1/256
+    int acc[PXT][CH];
+    int bias[PXT];
+#pragma unroll
+    for (int p = 0; p < PXT; ++p)
+    {
+        bias[p] = 0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            acc[p][c] = 0;
+    }
+    const size_t pix = (size_t)i * W + j;
+    for (int k = 0; k < K; ++k)
+    {
+        const uint4 e4 = *(const uint4*)((const uint32_t*)dec_fwd.p[k] + pix);
+        const uint32_t* sg = (const uint32_t*)signs.p[k];
+        const uint32_t ev[PXT] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+        for (int p = 0; p < PXT; ++p)
+        {
+            const uint32_t e = ev[p];
+            if (e & kFwdOutside)
+                continue;
+            if (e & kFwdSlow)
+            {
+                const short2 m = ((const short2*)raw_fwd.p[k])[pix + p];
+                float a[CH];
+                backproject_generic<CH>(sg, H, W, 4, m.x, m.y, g, a);
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    acc[p][c] += (int)(a[c] * 256.0f);
+                continue;
+            }
+            const uint32_t* s0 = sg + (e & kFwdCellMask);
+            const uint32_t ph = e >> kFwdPhaseShift; // flags are clear here
+            const uint4 wq = lutw[ph];
+            uint32_t v = s0[0] * wq.x;
+            v += s0[1] * wq.y;
+            v += s0[w] * wq.z;
+            v += s0[w + 1] * wq.w;
+            bias[p] += luts[ph];
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                acc[p][c] += (int)((v >> (10 * c)) & 1023u);
+        }
+    }
+
+    // ---- BTV regulariser from the LDS tile
+    float reg[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+        reg[e] = 0.0f;
+    const int lrow = ty + HALO;
+    const int lbase = tx * PXT * CH; // aligned window start (floats)
+    int ctr[NE];
+    {
+        int4 cv[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            cv[v] = *(const int4*)&tile[lrow * PITCH + lbase + 4 * v];
+        const int* cw = (const int*)cv;
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            ctr[e] = cw[OFF + HALO * CH + e];
+    }
+    if (lambda > 0)
+    {
+        int ind = 0;
+#pragma unroll
+        for (int m = 0; m <= 3; ++m)
+        {
+            int4 pv[NV], mv[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+            {
+                pv[v] = *(const int4*)&tile[(lrow + m) * PITCH + lbase + 4 * v];
+                mv[v] = *(const int4*)&tile[(lrow - m) * PITCH + lbase + 4 * v];
+            }
+            const int* pw = (const int*)pv;
+            const int* mw = (const int*)mv;
+#pragma unroll
+            for (int l = 3; l + m >= 0; --l, ++ind)
+            {
+                if (m == 0 && l == 0)
+                    continue; // both signs compare the pixel with itself: adds w * 0
+                const float wt = bw.w[ind];
+#pragma unroll
+                for (int e = 0; e < NE; ++e)
+                {
+                    const int c0 = OFF + HALO * CH + e;
+                    const int d = key_sign(ctr[e], pw[c0 + CH * l]) + key_sign(ctr[e], mw[c0 - CH * l]);
+                    // w * d is exact (d in -2..2), so the fused form rounds once, like acc += w * d
+                    reg[e] = __builtin_fmaf(wt, (float)d, reg[e]);
+                }
+            }
+        }
+    }
+
+    // ---- update
+    float outv[NE];
+#pragma unroll
+    for (int p = 0; p < PXT; ++p)
+    {
+        const bool interior = i >= HALO && i < H - HALO && (j + p) >= HALO && (j + p) < W - HALO;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+        {
+            const int e = p * CH + c;
+            float d = (float)(acc[p][c] - bias[p]) * 0.00390625f;
+            if (lambda > 0)
+            {
+                const float rg = interior ? reg[e] : 0.0f;
+                d = (float)((double)d + (double)rg * (-lambda));
+            }
+            outv[e] = (float)((double)key_float(ctr[e]) + (double)d * tau);
+        }
+    }
+    float4* D = (float4*)(X_out + pix * CH);
+#pragma unroll
+    for (int v = 0; v < NE / 4; ++v)
+        D[v] = make_float4(outv[4 * v], outv[4 * v + 1], outv[4 * v + 2], outv[4 * v + 3]);
 }
 
 // ---------------------------------------------------------------------------
@@ -454,6 +817,12 @@ int check_launch(const char* what)
     return 0;
 }
 
+// round the block count up to a multiple of 8 so that every XCD's range exists
+inline unsigned xcd_grid(unsigned n)
+{
+    return (n + 7u) & ~7u;
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------
@@ -467,12 +836,26 @@ int launch_relative_motions(const PtrList& fwd, const MutPtrList& rel, int n, in
 }
 
 int launch_build_maps(const float* rel, int rows, int cols, int scale, const CubicTables& t, int16_t* fwd_map,
-                      int16_t* bwd_map, hipStream_t st)
+                      int16_t* bwd_map, uint32_t* dec_fwd, uint32_t* dec_bwd, hipStream_t st)
 {
+    if ((dec_fwd || dec_bwd) && scale != 4)
+    {
+        set_error("build_maps: decoded maps exist for scale 4 only");
+        return 1;
+    }
     const dim3 b(64, 4);
     hipLaunchKernelGGL(k_build_maps, grid2d(cols * scale, rows * scale, b), b, 0, st, rel, rows, cols, scale, t,
-                       (short2*)fwd_map, (short2*)bwd_map);
+                       (short2*)fwd_map, (short2*)bwd_map, dec_fwd, dec_bwd);
     return check_launch("build_maps");
+}
+
+int launch_decode_maps(const int16_t* fwd_map, const int16_t* bwd_map, int hr_rows, int hr_cols, uint32_t* dec_fwd,
+                       uint32_t* dec_bwd, hipStream_t st)
+{
+    const dim3 b(64, 4);
+    hipLaunchKernelGGL(k_decode_maps, grid2d(hr_cols, hr_rows, b), b, 0, st, (const short2*)fwd_map,
+                       (const short2*)bwd_map, hr_rows, hr_cols, dec_fwd, dec_bwd);
+    return check_launch("decode_maps");
 }
 
 int launch_resize_cubic(const float* src, int srows, int scols, int ch, const CubicTables& t, float* dst, int drows,
@@ -504,42 +887,114 @@ int launch_btv_regularization(const float* src, int rows, int cols, int ch, cons
     return check_launch("btv_regularization");
 }
 
-int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const PtrList& bwd_maps, const PtrList& y,
-                        const MutPtrList& signs, int K, int scale, const GaussK& g, hipStream_t st)
+bool forward_fast_eligible(int hr_rows, int hr_cols, int ch, int scale, const GaussK& g)
 {
+    return scale == 4 && g.n == 5 && (ch == 1 || ch == 3) && hr_rows % 4 == 0 && hr_cols % 4 == 0 &&
+           (size_t)hr_rows * hr_cols < (1u << 30);
+}
+
+int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const PtrList& raw_bwd,
+                        const PtrList* dec_bwd, const PtrList& y, const MutPtrList& signs, int K, int scale,
+                        const GaussK& g, hipStream_t st)
+{
+    if (ch != 1 && ch != 3)
+    {
+        set_error("forward_sign: channels must be 1 or 3");
+        return 1;
+    }
+    if (dec_bwd && forward_fast_eligible(hr_rows, hr_cols, ch, scale, g))
+    {
+        const int w = hr_cols / 4, h = hr_rows / 4;
+        const int tiles_x = (w + 63) / 64, tiles_y = (h + 3) / 4;
+        const unsigned n_items = (unsigned)tiles_x * tiles_y * K;
+        const dim3 gr(xcd_grid(n_items)), b(256);
+        if (ch == 1)
+            hipLaunchKernelGGL(k_forward_sign_s4<1>, gr, b, 0, st, X, hr_rows, hr_cols, *dec_bwd, raw_bwd, y, signs, K,
+                               g, tiles_x, n_items);
+        else
+            hipLaunchKernelGGL(k_forward_sign_s4<3>, gr, b, 0, st, X, hr_rows, hr_cols, *dec_bwd, raw_bwd, y, signs, K,
+                               g, tiles_x, n_items);
+        return check_launch("forward_sign_s4");
+    }
     const dim3 b(64, 4);
     const dim3 gr = grid2d(hr_cols / scale, hr_rows / scale, b, K);
-    switch (ch)
-    {
-    case 1:
-        hipLaunchKernelGGL(k_forward_sign<1>, gr, b, 0, st, X, hr_rows, hr_cols, bwd_maps, y, signs, scale, g);
-        break;
-    case 3:
-        hipLaunchKernelGGL(k_forward_sign<3>, gr, b, 0, st, X, hr_rows, hr_cols, bwd_maps, y, signs, scale, g);
-        break;
-    default: set_error("forward_sign: channels must be 1 or 3"); return 1;
-    }
+    if (ch == 1)
+        hipLaunchKernelGGL(k_forward_sign<1>, gr, b, 0, st, X, hr_rows, hr_cols, raw_bwd, y, signs, scale, g);
+    else
+        hipLaunchKernelGGL(k_forward_sign<3>, gr, b, 0, st, X, hr_rows, hr_cols, raw_bwd, y, signs, scale, g);
     return check_launch("forward_sign");
 }
 
-int launch_backproject_update(const float* X, float* X_out, int hr_rows, int hr_cols, int ch, const PtrList& fwd_maps,
-                              const PtrList& signs, int K, int scale, const GaussK& g, const BtvW& w, double tau,
-                              double lambda, hipStream_t st)
+// The integer path needs every blur weight to be a multiple of 1/16 (true for
+// the sigma = 0 table {1,4,6,4,1}/16).
+static bool make_fast_weights(const GaussK& g, FastW& fw)
 {
+    if (g.n != 5)
+        return false;
+    int ki[3];
+    for (int i = 0; i < 3; ++i)
+    {
+        const float v = g.k[2 + i] * 16.0f;
+        if (!(v >= 0.0f && v <= 15.0f) || v != (float)(int)v || g.k[2 + i] != g.k[2 - i])
+            return false;
+        ki[i] = (int)v;
+    }
+    // per phase p = f & 3: slot A carries tap j = {0,-1,-2,+1}[p], slot B only exists for p == 2 (tap +2)
+    const int gA[4] = {ki[0], ki[1], ki[2], ki[1]};
+    const int gB[4] = {0, 0, ki[2], 0};
+    for (int py = 0; py < 4; ++py)
+        for (int px = 0; px < 4; ++px)
+        {
+            const int p = px | (py << 2);
+            fw.w[p][0] = gA[px] * gA[py];
+            fw.w[p][1] = gB[px] * gA[py];
+            fw.w[p][2] = gA[px] * gB[py];
+            fw.w[p][3] = gB[px] * gB[py];
+            fw.wsum[p] = fw.w[p][0] + fw.w[p][1] + fw.w[p][2] + fw.w[p][3];
+            if (2 * fw.wsum[p] > 1023u)
+                return false; // 10-bit fields
+        }
+    return true;
+}
+
+bool backproject_fast_eligible(int hr_rows, int hr_cols, int ch, int scale, const GaussK& g, const BtvW& w)
+{
+    FastW fw;
+    return scale == 4 && w.radius == 3 && (ch == 1 || ch == 3) && hr_rows % 4 == 0 && hr_cols % 4 == 0 &&
+           (size_t)(hr_rows / 4) * (hr_cols / 4) < (1u << 24) && make_fast_weights(g, fw);
+}
+
+int launch_backproject_update(const float* X, float* X_out, int hr_rows, int hr_cols, int ch, const PtrList& raw_fwd,
+                              const PtrList* dec_fwd, const PtrList& signs, int K, int scale, const GaussK& g,
+                              const BtvW& w, double tau, double lambda, hipStream_t st)
+{
+    if (ch != 1 && ch != 3)
+    {
+        set_error("backproject_update: channels must be 1 or 3");
+        return 1;
+    }
+    FastW fw;
+    if (dec_fwd && backproject_fast_eligible(hr_rows, hr_cols, ch, scale, g, w) && make_fast_weights(g, fw))
+    {
+        const int tiles_x = (hr_cols + 63) / 64, tiles_y = (hr_rows + 15) / 16;
+        const unsigned n_tiles = (unsigned)tiles_x * tiles_y;
+        const dim3 gr(xcd_grid(n_tiles)), b(256);
+        if (ch == 1)
+            hipLaunchKernelGGL(k_backproject_update_s4<1>, gr, b, 0, st, X, X_out, hr_rows, hr_cols, *dec_fwd, raw_fwd,
+                               signs, K, g, fw, w, tau, lambda, tiles_x, n_tiles);
+        else
+            hipLaunchKernelGGL(k_backproject_update_s4<3>, gr, b, 0, st, X, X_out, hr_rows, hr_cols, *dec_fwd, raw_fwd,
+                               signs, K, g, fw, w, tau, lambda, tiles_x, n_tiles);
+        return check_launch("backproject_update_s4");
+    }
     const dim3 b(64, 4);
     const dim3 gr = grid2d(hr_cols, hr_rows, b);
-    switch (ch)
-    {
-    case 1:
-        hipLaunchKernelGGL(k_backproject_update<1>, gr, b, 0, st, X, X_out, hr_rows, hr_cols, fwd_maps, signs, K,
-                           scale, g, w, tau, lambda);
-        break;
-    case 3:
-        hipLaunchKernelGGL(k_backproject_update<3>, gr, b, 0, st, X, X_out, hr_rows, hr_cols, fwd_maps, signs, K,
-                           scale, g, w, tau, lambda);
-        break;
-    default: set_error("backproject_update: channels must be 1 or 3"); return 1;
-    }
+    if (ch == 1)
+        hipLaunchKernelGGL(k_backproject_update<1>, gr, b, 0, st, X, X_out, hr_rows, hr_cols, raw_fwd, signs, K, scale,
+                           g, w, tau, lambda);
+    else
+        hipLaunchKernelGGL(k_backproject_update<3>, gr, b, 0, st, X, X_out, hr_rows, hr_cols, raw_fwd, signs, K, scale,
+                           g, w, tau, lambda);
     return check_launch("backproject_update");
 }
 

@@ -13,6 +13,8 @@ namespace
 thread_local std::string g_error;
 }
 
+int g_kernel_path = 0;
+
 void set_error(const std::string& msg)
 {
     g_error = msg;
@@ -211,17 +213,25 @@ CubicTables CubicTablesDev::view() const
 int Solver::ensure(int K, int rows, int cols, int ch, int scale, hipStream_t st)
 {
     const size_t hr_px = (size_t)rows * scale * cols * scale;
+    // HR images carry one extra zero pixel; sign planes one extra row and word
+    // (the specialised kernels read, with weight 0, one cell past the last)
+    const size_t x_bytes = (hr_px + 1) * ch * sizeof(float);
+    const size_t sign_bytes = ((size_t)(rows + 1) * cols + 1) * sizeof(uint32_t);
+    const size_t rel_bytes = (size_t)rows * cols * 2 * sizeof(float);
+    const bool dec = scale == 4 && g_kernel_path == 0;
     if ((int)fwd_maps_.size() < K)
     {
         fwd_maps_.resize(K);
         bwd_maps_.resize(K);
+        dec_fwd_.resize(K);
+        dec_bwd_.resize(K);
         signs_.resize(K);
         rel_.resize(K);
     }
-    bool grow = x_[0].capacity() < hr_px * ch * sizeof(float);
+    bool grow = x_[0].capacity() < x_bytes;
     for (int k = 0; k < K && !grow; ++k)
-        grow = fwd_maps_[k].capacity() < hr_px * 4 || signs_[k].capacity() < (size_t)rows * cols * 4 ||
-               rel_[k].capacity() < (size_t)rows * cols * 2 * sizeof(float);
+        grow = fwd_maps_[k].capacity() < hr_px * 4 || signs_[k].capacity() < sign_bytes ||
+               rel_[k].capacity() < rel_bytes || (dec && dec_fwd_[k].capacity() < hr_px * 4);
     if (grow)
         SRX_HIP(hipStreamSynchronize(st)); // buffers about to be freed may still be in use
     for (int k = 0; k < K; ++k)
@@ -230,14 +240,28 @@ int Solver::ensure(int K, int rows, int cols, int ch, int scale, hipStream_t st)
             return rc;
         if (int rc = bwd_maps_[k].reserve(hr_px * 4))
             return rc;
-        if (int rc = signs_[k].reserve((size_t)rows * cols * 4))
-            return rc;
-        if (int rc = rel_[k].reserve((size_t)rows * cols * 2 * sizeof(float)))
+        if (dec)
+        {
+            if (int rc = dec_fwd_[k].reserve(hr_px * 4))
+                return rc;
+            if (int rc = dec_bwd_[k].reserve(hr_px * 4))
+                return rc;
+        }
+        if (signs_[k].capacity() < sign_bytes)
+        {
+            if (int rc = signs_[k].reserve(sign_bytes))
+                return rc;
+            SRX_HIP(hipMemsetAsync(signs_[k].get(), 0, sign_bytes, st));
+        }
+        if (int rc = rel_[k].reserve(rel_bytes))
             return rc;
     }
     for (int i = 0; i < 2; ++i)
-        if (int rc = x_[i].reserve(hr_px * ch * sizeof(float)))
+    {
+        if (int rc = x_[i].reserve(x_bytes))
             return rc;
+        SRX_HIP(hipMemsetAsync(x_[i].as<float>() + hr_px * ch, 0, ch * sizeof(float), st));
+    }
     return tables_.ensure(rows, cols, rows * scale, cols * scale, st);
 }
 
@@ -245,6 +269,8 @@ void Solver::release()
 {
     fwd_maps_.clear();
     bwd_maps_.clear();
+    dec_fwd_.clear();
+    dec_bwd_.clear();
     signs_.clear();
     rel_.clear();
     x_[0].release();
@@ -301,15 +327,21 @@ int Solver::run(const float* const* y, const float* const* rel, int K, int base_
     }
 
     const CubicTables t = tables_.view();
-    PtrList fwd{}, bwd{}, ys{}, sg{};
+    const bool auto_path = g_kernel_path == 0;
+    const bool fastA = auto_path && forward_fast_eligible((int)R, (int)C, ch, s, gauss_);
+    const bool fastB = auto_path && backproject_fast_eligible((int)R, (int)C, ch, s, gauss_, btv_);
+    PtrList fwd{}, bwd{}, dfwd{}, dbwd{}, ys{}, sg{};
     MutPtrList sgm{};
     for (int k = 0; k < K; ++k)
     {
         if (int rc = launch_build_maps(rel[k], rows, cols, s, t, fwd_maps_[k].as<int16_t>(),
-                                       bwd_maps_[k].as<int16_t>(), st))
+                                       bwd_maps_[k].as<int16_t>(), fastB ? dec_fwd_[k].as<uint32_t>() : nullptr,
+                                       fastA ? dec_bwd_[k].as<uint32_t>() : nullptr, st))
             return rc;
         fwd.p[k] = fwd_maps_[k].get();
         bwd.p[k] = bwd_maps_[k].get();
+        dfwd.p[k] = dec_fwd_[k].get();
+        dbwd.p[k] = dec_bwd_[k].get();
         ys.p[k] = y[k];
         sg.p[k] = signs_[k].get();
         sgm.p[k] = signs_[k].get();
@@ -322,10 +354,12 @@ int Solver::run(const float* const* y, const float* const* rel, int K, int base_
 
     for (int it = 0; it < p.iterations; ++it)
     {
-        if (int rc = launch_forward_sign(x_[cur_].as<float>(), (int)R, (int)C, ch, bwd, ys, sgm, K, s, gauss_, st))
+        if (int rc = launch_forward_sign(x_[cur_].as<float>(), (int)R, (int)C, ch, bwd, fastA ? &dbwd : nullptr, ys,
+                                         sgm, K, s, gauss_, st))
             return rc;
         if (int rc = launch_backproject_update(x_[cur_].as<float>(), x_[cur_ ^ 1].as<float>(), (int)R, (int)C, ch,
-                                               fwd, sg, K, s, gauss_, btv_, p.tau, p.lambda, st))
+                                               fwd, fastB ? &dfwd : nullptr, sg, K, s, gauss_, btv_, p.tau, p.lambda,
+                                               st))
             return rc;
         cur_ ^= 1;
     }

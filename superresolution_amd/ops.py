@@ -3,7 +3,8 @@
 torch only supplies device memory and the current stream; every function here
 calls a srx_k_* / srx_run C-ABI symbol and raises if the library is missing.
 Layouts: images (rows, cols, ch) float32; index maps (rows, cols, 2) int16
-(x, y); signs (rows, cols, 4) int8.
+(x, y); signs (rows, cols) int32 words holding sign+1 of channel c in bits
+10c..10c+1.
 """
 from __future__ import annotations
 
@@ -88,7 +89,7 @@ def forward_sign(X: torch.Tensor, bwd_map: torch.Tensor, y: torch.Tensor, scale:
     _chk(y, torch.float32, "y")
     X3 = X if X.dim() == 3 else X[:, :, None]
     H, W, ch = X3.shape
-    sign = torch.zeros((H // scale, W // scale, 4), dtype=torch.int8, device=X.device)
+    sign = torch.zeros((H // scale, W // scale), dtype=torch.int32, device=X.device)
     g = np.ascontiguousarray(gauss, np.float32)
     L.check(L.lib().srx_k_forward_sign(X3.data_ptr(), H, W, ch, bwd_map.data_ptr(), y.data_ptr(), scale, _fptr(g),
                                        g.size, sign.data_ptr(), _stream()))
@@ -103,7 +104,7 @@ def backproject_update(X: torch.Tensor, fwd_maps: Sequence[torch.Tensor], signs:
     for m in fwd_maps:
         _chk(m, torch.int16, "fwd_map")
     for s in signs:
-        _chk(s, torch.int8, "sign")
+        _chk(s, torch.int32, "sign")
     out = torch.empty_like(X3)
     g = np.ascontiguousarray(gauss, np.float32)
     w = np.ascontiguousarray(w, np.float32)
@@ -123,6 +124,28 @@ def crop_convert(X: torch.Tensor, border: int, to_8u: bool) -> torch.Tensor:
     L.check(L.lib().srx_k_crop_convert(X3.data_ptr(), H, W, ch, border, out.data_ptr(),
                                        L.SRX_8U if to_8u else L.SRX_32F, _stream()))
     return out if X.dim() == 3 else out[:, :, 0]
+
+
+def pack_signs(s: np.ndarray) -> np.ndarray:
+    """(rows, cols, ch) array of -1/0/1 -> the packed int32 sign words."""
+    s = np.asarray(s)
+    if s.ndim == 2:
+        s = s[:, :, None]
+    out = np.zeros(s.shape[:2], np.int32)
+    for c in range(s.shape[2]):
+        out |= (s[:, :, c].astype(np.int32) + 1) << (10 * c)
+    return out
+
+
+def unpack_signs(words, ch: int) -> np.ndarray:
+    """Packed int32 sign words -> (rows, cols, ch) int8 array of -1/0/1."""
+    wd = np.asarray(words).astype(np.int64)
+    return np.stack([((wd >> (10 * c)) & 3) - 1 for c in range(ch)], axis=-1).astype(np.int8)
+
+
+def set_kernel_path(path: int) -> None:
+    """0: specialised kernels where the parameters allow (default); 1: generic kernels only."""
+    L.check(L.lib().srx_set_kernel_path(path))
 
 
 def _solve(fn_name: str, sr, y: Sequence[torch.Tensor], motions: Sequence[torch.Tensor], base_idx: int,

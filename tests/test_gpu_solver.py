@@ -16,6 +16,17 @@ from conftest import smooth_motion
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[0, 1], ids=["auto", "generic"])
+def kernel_path(request):
+    """Every test runs twice: with the specialised kernels enabled (they are picked where the parameters allow)
+    and with the generic kernels forced."""
+    from superresolution_amd import ops as _ops
+
+    _ops.set_kernel_path(request.param)
+    yield request.param
+    _ops.set_kernel_path(0)
+
+
 def dev(a):
     import torch
 
@@ -100,7 +111,7 @@ def test_fixed_point_kat(rng):
     zero = np.zeros((rows, cols, 2), np.float32)
     fm, bm = ops.build_maps(dev(zero), s)
     sg = ops.forward_sign(dev(X0), bm, dev(y), s, gk)
-    assert not sg.cpu().numpy().any()
+    assert np.array_equal(sg.cpu().numpy(), ops.pack_signs(np.zeros((rows, cols, 1))))
     w = oracle.calc_btv_weights(7, 0.7)
     X1 = ops.backproject_update(dev(X0), [fm], [sg], s, gk, 7, w, 1.3, 0.0)
     assert np.array_equal(X1.cpu().numpy(), X0)

@@ -13,6 +13,17 @@ from conftest import smooth_motion
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[0, 1], ids=["auto", "generic"])
+def kernel_path(request):
+    """Every test runs twice: with the specialised kernels enabled (they are picked where the parameters allow)
+    and with the generic kernels forced."""
+    from superresolution_amd import ops as _ops
+
+    _ops.set_kernel_path(request.param)
+    yield request.param
+    _ops.set_kernel_path(0)
+
+
 @pytest.fixture(scope="module")
 def ops():
     import torch  # noqa: F401
@@ -122,8 +133,8 @@ def test_forward_sign(ops, rng, rows, cols, ch, scale, n, sigma):
     assert set(np.unique(ref)) == {-1.0, 0.0, 1.0}
     _, bwd_map = ops.build_maps(dev(rel), scale)
     got = host(ops.forward_sign(dev(X), bwd_map, dev(y), scale, gk))
-    assert np.array_equal(ref.astype(np.int8), got[:, :, :ch])
-    assert not got[:, :, ch:].any()
+    assert np.array_equal(ref.astype(np.int8).reshape(rows, cols, ch), ops.unpack_signs(got, ch))
+    assert np.array_equal(got, ops.pack_signs(ref.reshape(rows, cols, ch)))
 
 
 def _backproject_ref(X, signs, fwd_floats, scale, gk, B, w, tau, lam):
@@ -165,9 +176,7 @@ def test_backproject_update(ops, rng, rows, cols, ch, scale, n, sigma, K, lam):
         fwd_floats.append(f)
         fm, _ = ops.build_maps(dev(rel), scale)
         fwd_maps.append(fm)
-        s4 = np.zeros((rows, cols, 4), np.int8)
-        s4[:, :, :ch] = s.astype(np.int8)
-        signs_dev.append(dev(s4))
+        signs_dev.append(dev(ops.pack_signs(s)))
     ref = _backproject_ref(X, signs, fwd_floats, scale, gk, B, w, tau, lam)
     got = host(ops.backproject_update(dev(X), fwd_maps, signs_dev, scale, gk, B, w, tau, lam))
     assert np.array_equal(ref, got)
