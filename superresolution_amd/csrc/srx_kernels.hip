@@ -22,6 +22,8 @@
 // blur size, BTV size) and specialised ones (scale 4, 5-tap blur, BTV 7).
 #include "srx_common.h"
 
+#include <cstring>
+
 namespace srx
 {
 
@@ -30,10 +32,19 @@ namespace
 
 // forward decoded-map entry (scale 4, 5-tap blur): a target (fx, fy) touches at
 // most the 2x2 block of LR sign cells whose top-left cell is `cell`
-constexpr uint32_t kFwdCellMask = 0x00FFFFFFu; // bits 0..23  cell index (row*w + col)
-constexpr int kFwdPhaseShift = 24;             // bits 24..25 fx & 3, bits 26..27 fy & 3
-constexpr uint32_t kFwdSlow = 0x40000000u;     // target within 2 px of the image edge: reflect101 in play
-constexpr uint32_t kFwdOutside = 0x80000000u;  // target outside the image: contributes 0
+//   bits 0..23   cell index (row*w + col)
+//   bits 24..28  weight-table index: 0..15 = (fx & 3) | (fy & 3) << 2,
+//                16 = target outside the image (all weights 0),
+//                17 = target within 2 px of the image edge, where reflect101
+//                     comes into play (weights 0 here; evaluated generically)
+constexpr uint32_t kFwdCellMask = 0x00FFFFFFu;
+constexpr int kFwdLutShift = 24;
+constexpr uint32_t kFwdLutOutside = 16, kFwdLutSlow = 17;
+constexpr int kFwdLutSize = 18;
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+// volatile LDS vector access keeps 16-byte ds_read_b128 from being split into narrower reads
+typedef __attribute__((address_space(3))) const volatile v4i lds_cv4i;
 
 __device__ __forceinline__ int reflect101(int p, int len)
 {
@@ -133,12 +144,12 @@ __device__ __forceinline__ uint32_t decode_bwd(int bx, int by, int R, int C)
 __device__ __forceinline__ uint32_t decode_fwd(int fx, int fy, int R, int C)
 {
     if ((unsigned)fx >= (unsigned)C || (unsigned)fy >= (unsigned)R)
-        return kFwdOutside;
+        return kFwdLutOutside << kFwdLutShift;
     if (fx < 2 || fx > C - 3 || fy < 2 || fy > R - 3)
-        return kFwdSlow;
+        return kFwdLutSlow << kFwdLutShift;
     const int px = fx & 3, py = fy & 3;
     const int col = (fx >> 2) + (px == 3), row = (fy >> 2) + (py == 3);
-    return (uint32_t)(row * (C >> 2) + col) | ((uint32_t)(px | (py << 2)) << kFwdPhaseShift);
+    return (uint32_t)(row * (C >> 2) + col) | ((uint32_t)(px | (py << 2)) << kFwdLutShift);
 }
 
 // upscaleMotions + buildMotionMaps + remap's float->short index conversion
@@ -490,76 +501,119 @@ __global__ void k_backproject_update(const float* __restrict__ X, float* __restr
 // Specialised kernels: scale 4, 5-tap blur (and BTV kernel size 7 for the update)
 // ===========================================================================
 
-// Forward chain for one 64x4 tile of LR pixels and one window frame per block.
-// Work list = (tile, k) with k fastest, split into one contiguous range per XCD
-// so that the K gathers over a tile of X run back to back against one L2.
-// Per LR pixel: 5 rows x 5 taps; map entries come as one 8-byte and one 16-byte
-// load per row, X pixels as one CH-float gather per tap.
+// value of lane-1 / lane+1 within the 16-lane DPP row (0 at the row's ends)
+__device__ __forceinline__ float dpp_from_left(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111 /* row_shr:1 */, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_from_right(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101 /* row_shl:1 */, 0xF, 0xF, true));
+}
+
+// Forward chain sign(y_k - D H M_k X), one wave per (strip of 28 LR columns,
+// group of LR rows, window frame).
+//
+// Lanes own HR columns, not LR pixels: lane p of a 16-lane DPP row holds the
+// warped pixels of two adjacent HR columns (E = even, O = odd register), so a
+// wave's map reads and X gathers run over consecutive addresses.  The 5-tap row
+// pass at the even column of every odd lane is
+//     E*k0 + (O[p-1] + O[p])*k1 + (E[p-1] + E[p+1])*k2
+// with the neighbours fetched by DPP row shifts; 7 LR pixels per DPP row, 28
+// per wave.  The wave walks down its LR rows keeping the five row-pass results
+// of the current LR row in registers (four new HR rows per LR row).
+// Work items are ordered frame-fastest so that the waves gathering from one
+// region of X run together on one CU / XCD.
+constexpr int kFwdRowsPerWave = 6;
+constexpr int kFwdStrip = 28;
+
 template <int CH>
 __global__ __launch_bounds__(256) void k_forward_sign_s4(const float* __restrict__ X, int H, int W, PtrList dec_bwd,
-                                                          PtrList raw_bwd, PtrList ys, MutPtrList signs, int K,
-                                                          GaussK g, int tiles_x, unsigned n_items)
+                                                          PtrList ys, MutPtrList signs, int K, GaussK g,
+                                                          int strips_x, unsigned n_items, unsigned n_blocks)
 {
-    const unsigned item = xcd_contiguous(blockIdx.x, n_items);
+    const unsigned item = xcd_contiguous(blockIdx.x, n_blocks) * 4 + (threadIdx.x >> 6);
     if (item >= n_items)
         return;
     const int k = item % K;
     const unsigned tile = item / K;
+    const int strip = tile % strips_x, rg = tile / strips_x;
     const int h = H >> 2, w = W >> 2;
-    const int x = (tile % tiles_x) * 64 + (threadIdx.x & 63);
-    const int y = (tile / tiles_x) * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h)
-        return;
-    uint32_t* out = (uint32_t*)signs.p[k] + (size_t)y * w + x;
-    if (x == 0 || y == 0)
-    {
-        // taps reach over the left/top edge: reflect101 path
-        *out = forward_sign_generic<CH>(X, H, W, (const short2*)raw_bwd.p[k], (const float*)ys.p[k], x, y, 4, g);
-        return;
-    }
-    const uint32_t* map = (const uint32_t*)dec_bwd.p[k] + (size_t)(4 * y - 2) * W + (4 * x - 2);
+    const int lane = threadIdx.x & 63, j = lane >> 4, q = lane & 15;
+    const int x0 = strip * kFwdStrip, y0 = rg * kFwdRowsPerWave;
+    const int y1 = min(y0 + kFwdRowsPerWave, h);
+
+    const int col0 = 4 * x0 - 2 + 28 * j + 2 * q; // even register's HR column; the odd register holds col0 + 1
+    const int cA = reflect101(col0, W), cB = reflect101(col0 + 1, W);
+    const bool pair = (cB == cA + 1);             // plain interior lane: one 8-byte map load
+    const int x = x0 + 7 * j + (q >> 1);          // LR pixel centred on col0 (odd lanes 1..13)
+    const bool owner = (q & 1) && q <= 13 && x < w;
+
+    const uint32_t* map = (const uint32_t*)dec_bwd.p[k];
     const float k0 = g.k[2], k1 = g.k[3], k2 = g.k[4];
-    float rr[5][CH];
-#pragma unroll
-    for (int r = 0; r < 5; ++r)
-    {
-        const uint32_t* mr = map + (size_t)r * W;
-        const uint2 ma = *(const uint2*)mr;       // columns 4x-2, 4x-1
-        const uint4 mb = *(const uint4*)(mr + 2); // columns 4x .. 4x+3
-        const float* pm2 = X + (size_t)ma.x * CH;
-        const float* pm1 = X + (size_t)ma.y * CH;
-        const float* pc = X + (size_t)mb.x * CH;
-        const float* pp1 = X + (size_t)mb.y * CH;
-        const float* pp2 = X + (size_t)mb.z * CH;
+
+    auto row_pass = [&](int Y, float (&out)[CH]) {
+        const uint32_t* mr = map + (size_t)reflect101(Y, H) * W;
+        uint32_t ia, ib;
+        if (pair)
+        {
+            const uint2 m2 = *(const uint2*)(mr + cA);
+            ia = m2.x, ib = m2.y;
+        }
+        else
+        {
+            ia = mr[cA];
+            ib = mr[cB];
+        }
+        const float* pe = X + (size_t)ia * CH;
+        const float* po = X + (size_t)ib * CH;
 #pragma unroll
         for (int c = 0; c < CH; ++c)
         {
-            float s = pc[c] * k0;
-            s += (pm1[c] + pp1[c]) * k1;
-            s += (pm2[c] + pp2[c]) * k2;
-            rr[r][c] = s;
+            const float e = pe[c], o = po[c];
+            const float u = dpp_from_left(o) + o;                  // columns col0-1, col0+1
+            const float v = dpp_from_left(e) + dpp_from_right(e);  // columns col0-2, col0+2
+            float s = e * k0;
+            s += u * k1;
+            s += v * k2;
+            out[c] = s;
         }
-    }
-    const float* yp = (const float*)ys.p[k] + ((size_t)y * w + x) * CH;
-    uint32_t sg = 0;
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
+    };
+
+    float rr[5][CH];
+    row_pass(4 * y0 - 2, rr[0]);
+    for (int y = y0; y < y1; ++y)
     {
-        float s = rr[2][c] * k0;
-        s += (rr[1][c] + rr[3][c]) * k1;
-        s += (rr[0][c] + rr[4][c]) * k2;
-        sg |= (uint32_t)((int)dsign(yp[c], s) + 1) << (10 * c);
+#pragma unroll
+        for (int r = 1; r < 5; ++r)
+            row_pass(4 * y - 2 + r, rr[r]);
+        if (owner)
+        {
+            const float* yp = (const float*)ys.p[k] + ((size_t)y * w + x) * CH;
+            uint32_t sg = 0;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+            {
+                float s = rr[2][c] * k0;
+                s += (rr[1][c] + rr[3][c]) * k1;
+                s += (rr[0][c] + rr[4][c]) * k2;
+                sg |= (uint32_t)((int)dsign(yp[c], s) + 1) << (10 * c);
+            }
+            ((uint32_t*)signs.p[k])[(size_t)y * w + x] = sg;
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            rr[0][c] = rr[4][c];
     }
-    *out = sg;
 }
 
 // Integer weights of the transposed 5-tap blur for dyadic kernels (k*16 integer):
-// per phase pair (fx&3, fy&3) the weights of the 2x2 block of sign cells, in
-// units of 1/256, and their sum.
+// per weight-table index the weights of the 2x2 block of sign cells, in units of
+// 1/256, and their sum (entries 16 and 17 are all zero).
 struct FastW
 {
-    uint32_t w[16][4]; // [px | py << 2][AA, AB, BA, BB]
-    uint32_t wsum[16];
+    uint32_t w[kFwdLutSize][4]; // [AA, AB, BA, BB]
+    uint32_t wsum[kFwdLutSize];
 };
 
 // order-preserving float <-> int key (an involution); -0 is folded into +0 so
@@ -584,15 +638,18 @@ __device__ __forceinline__ int key_sign(int a, int b)
 
 // Back-projection of all K frames + BTV regulariser + update for one 64x16 tile
 // of HR pixels per block; each thread owns 4 consecutive pixels of one row.
-//  * per frame: one 16-byte load of 4 decoded forward-map entries, then per pixel
-//    the 2x2 block of sign cells times the phase's integer weights (exact for
-//    dyadic blur kernels: every partial sum is a multiple of 1/256)
+//  * per frame: one 16-byte load of 4 decoded forward-map entries (fetched one
+//    frame ahead), then per pixel the 2x2 block of sign cells times the entry's
+//    integer weights.  Exact for dyadic blur kernels: every partial sum is a
+//    multiple of 1/256.  The loop is branch-free (entries outside the image carry
+//    zero weights) so that all gathers of a frame are in flight together; the
+//    rare targets next to the image edge are added by a second, generic pass.
 //  * BTV: the tile of X (+3 px halo) sits in LDS as order-preserving integer
 //    keys; sign(a-b) is a saturating subtract and a clamp; accumulation order is
 //    the reference's (lib/src/btv_l1.cpp:221-233).  NaN pixels are ordered as
 //    large values instead of comparing unordered.
 template <int CH>
-__global__ __launch_bounds__(256) void k_backproject_update_s4(const float* __restrict__ X, float* __restrict__ X_out,
+__global__ __launch_bounds__(256, 4) void k_backproject_update_s4(const float* __restrict__ X, float* __restrict__ X_out,
                                                                 int H, int W, PtrList dec_fwd, PtrList raw_fwd,
                                                                 PtrList signs, int K, GaussK g, FastW fw, BtvW bw,
                                                                 double tau, double lambda, int tiles_x,
@@ -608,8 +665,8 @@ __global__ __launch_bounds__(256) void k_backproject_update_s4(const float* __re
     constexpr int OFF = CH == 3 ? 3 : 1;       // first needed float within the aligned window
     constexpr int NE = PXT * CH;               // outputs per thread
     __shared__ __attribute__((aligned(16))) int tile[LROWS * PITCH];
-    __shared__ uint4 lutw[16];
-    __shared__ uint32_t luts[16];
+    __shared__ uint4 lutw[kFwdLutSize];
+    __shared__ uint32_t luts[kFwdLutSize];
 
     const unsigned t = xcd_contiguous(blockIdx.x, n_tiles);
     if (t >= n_tiles)
@@ -618,8 +675,16 @@ __global__ __launch_bounds__(256) void k_backproject_update_s4(const float* __re
     const int tid = threadIdx.x;
     const int tx = tid & (TXN - 1), ty = tid >> 4;
     const int w = W >> 2;
+    const int i = min(i0 + ty, H - 1), j = min(j0 + tx * PXT, W - PXT); // clamped; stores are masked below
+    const bool live = (i0 + ty) < H && (j0 + tx * PXT) < W; // W is a multiple of 4: a thread's pixels are all in or all out
+    const size_t pix = (size_t)i * W + j;
 
-    if (tid < 16)
+    // first frame's map entries: issued before the tile is staged
+    uint4 cur = make_uint4(0, 0, 0, 0);
+    if (K > 0)
+        cur = *(const uint4*)((const uint32_t*)dec_fwd.p[0] + pix);
+
+    if (tid < kFwdLutSize)
     {
         lutw[tid] = make_uint4(fw.w[tid][0], fw.w[tid][1], fw.w[tid][2], fw.w[tid][3]);
         luts[tid] = fw.wsum[tid];
@@ -633,67 +698,16 @@ __global__ __launch_bounds__(256) void k_backproject_update_s4(const float* __re
             const int r = idx / V4, c4 = idx - r * V4;
             const int gi = i0 - HALO + r;
             const int f0 = (j0 - HL) * CH + 4 * c4;
-            int4 kv = make_int4(0, 0, 0, 0);
+            v4i kv = {0, 0, 0, 0};
             if (gi >= 0 && gi < H && f0 >= 0 && f0 + 3 < rowf)
             {
                 const float4 v = *(const float4*)(X + (size_t)gi * rowf + f0);
-                kv = make_int4(float_key(v.x), float_key(v.y), float_key(v.z), float_key(v.w));
+                kv = v4i{float_key(v.x), float_key(v.y), float_key(v.z), float_key(v.w)};
             }
-            *(int4*)&tile[r * PITCH + 4 * c4] = kv;
+            *(v4i*)&tile[r * PITCH + 4 * c4] = kv;
         }
     }
     __syncthreads();
-
-    const int i = i0 + ty, j = j0 + tx * PXT;
-    if (i >= H || j >= W)
-        return; // W is a multiple of 4: a thread's 4 pixels are all inside or all outside
-
-    // ---- sum over frames of M^T H^T D^T sign, in units of 1/256
-    int acc[PXT][CH];
-    int bias[PXT];
-#pragma unroll
-    for (int p = 0; p < PXT; ++p)
-    {
-        bias[p] = 0;
-#pragma unroll
-        for (int c = 0; c < CH; ++c)
-            acc[p][c] = 0;
-    }
-    const size_t pix = (size_t)i * W + j;
-    for (int k = 0; k < K; ++k)
-    {
-        const uint4 e4 = *(const uint4*)((const uint32_t*)dec_fwd.p[k] + pix);
-        const uint32_t* sg = (const uint32_t*)signs.p[k];
-        const uint32_t ev[PXT] = {e4.x, e4.y, e4.z, e4.w};
-#pragma unroll
-        for (int p = 0; p < PXT; ++p)
-        {
-            const uint32_t e = ev[p];
-            if (e & kFwdOutside)
-                continue;
-            if (e & kFwdSlow)
-            {
-                const short2 m = ((const short2*)raw_fwd.p[k])[pix + p];
-                float a[CH];
-                backproject_generic<CH>(sg, H, W, 4, m.x, m.y, g, a);
-#pragma unroll
-                for (int c = 0; c < CH; ++c)
-                    acc[p][c] += (int)(a[c] * 256.0f);
-                continue;
-            }
-            const uint32_t* s0 = sg + (e & kFwdCellMask);
-            const uint32_t ph = e >> kFwdPhaseShift; // flags are clear here
-            const uint4 wq = lutw[ph];
-            uint32_t v = s0[0] * wq.x;
-            v += s0[1] * wq.y;
-            v += s0[w] * wq.z;
-            v += s0[w + 1] * wq.w;
-            bias[p] += luts[ph];
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-                acc[p][c] += (int)((v >> (10 * c)) & 1023u);
-        }
-    }
 
     // ---- BTV regulariser from the LDS tile
     float reg[NE];
@@ -701,30 +715,29 @@ __global__ __launch_bounds__(256) void k_backproject_update_s4(const float* __re
     for (int e = 0; e < NE; ++e)
         reg[e] = 0.0f;
     const int lrow = ty + HALO;
-    const int lbase = tx * PXT * CH; // aligned window start (floats)
+    lds_cv4i* tp = (lds_cv4i*)tile + (lrow * PITCH + tx * PXT * CH) / 4; // aligned window start of the centre row
+    constexpr int RV = PITCH / 4;                                        // vectors per LDS row
+    v4i cv[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        cv[v] = tp[v];
+    const int* cw = (const int*)cv;
     int ctr[NE];
-    {
-        int4 cv[NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v)
-            cv[v] = *(const int4*)&tile[lrow * PITCH + lbase + 4 * v];
-        const int* cw = (const int*)cv;
-#pragma unroll
-        for (int e = 0; e < NE; ++e)
-            ctr[e] = cw[OFF + HALO * CH + e];
-    }
+    for (int e = 0; e < NE; ++e)
+        ctr[e] = cw[OFF + HALO * CH + e];
     if (lambda > 0)
     {
         int ind = 0;
 #pragma unroll
         for (int m = 0; m <= 3; ++m)
         {
-            int4 pv[NV], mv[NV];
+            v4i pv[NV], mv[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v)
             {
-                pv[v] = *(const int4*)&tile[(lrow + m) * PITCH + lbase + 4 * v];
-                mv[v] = *(const int4*)&tile[(lrow - m) * PITCH + lbase + 4 * v];
+                pv[v] = m == 0 ? cv[v] : tp[m * RV + v];
+                mv[v] = m == 0 ? cv[v] : tp[-m * RV + v];
             }
             const int* pw = (const int*)pv;
             const int* mw = (const int*)mv;
@@ -743,10 +756,77 @@ __global__ __launch_bounds__(256) void k_backproject_update_s4(const float* __re
                     reg[e] = __builtin_fmaf(wt, (float)d, reg[e]);
                 }
             }
+            // keep the next row pair's LDS reads behind this pair's arithmetic: hoisting them
+            // would hold several 36-register windows live at once
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- sum over frames of M^T H^T D^T sign, in units of 1/256
+    int acc[PXT][CH];
+    int bias[PXT];
+    uint32_t slow = 0;
+#pragma unroll
+    for (int p = 0; p < PXT; ++p)
+    {
+        bias[p] = 0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            acc[p][c] = 0;
+    }
+    for (int k = 0; k < K; ++k)
+    {
+        uint4 nxt = cur;
+        if (k + 1 < K)
+            nxt = *(const uint4*)((const uint32_t*)dec_fwd.p[k + 1] + pix);
+        const uint32_t* sg = (const uint32_t*)signs.p[k];
+        const uint32_t ev[PXT] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+        for (int p = 0; p < PXT; ++p)
+        {
+            const uint32_t e = ev[p];
+            const uint32_t* s0 = sg + (e & kFwdCellMask);
+            const uint32_t li = e >> kFwdLutShift;
+            const uint4 wq = lutw[li];
+            uint32_t v = s0[0] * wq.x;
+            v += s0[1] * wq.y;
+            v += s0[w] * wq.z;
+            v += s0[w + 1] * wq.w;
+            bias[p] += luts[li];
+            slow |= (li == kFwdLutSlow) ? 1u : 0u;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                acc[p][c] += (int)((v >> (10 * c)) & 1023u);
+        }
+        cur = nxt;
+    }
+    if (slow)
+    {
+        // targets within 2 px of the image edge: generic evaluation with reflect101
+        for (int k = 0; k < K; ++k)
+        {
+            const uint32_t* sg = (const uint32_t*)signs.p[k];
+            const uint32_t* de = (const uint32_t*)dec_fwd.p[k] + pix;
+#pragma unroll 1
+            for (int pp = 0; pp < PXT; ++pp)
+            {
+                if ((de[pp] >> kFwdLutShift) != kFwdLutSlow)
+                    continue;
+                const short2 m = ((const short2*)raw_fwd.p[k])[pix + pp];
+                float a[CH];
+                backproject_generic<CH>(sg, H, W, 4, m.x, m.y, g, a);
+#pragma unroll
+                for (int p = 0; p < PXT; ++p)
+#pragma unroll
+                    for (int c = 0; c < CH; ++c)
+                        acc[p][c] += p == pp ? (int)(a[c] * 256.0f) : 0;
+            }
         }
     }
 
     // ---- update
+    if (!live)
+        return;
     float outv[NE];
 #pragma unroll
     for (int p = 0; p < PXT; ++p)
@@ -905,15 +985,17 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
     if (dec_bwd && forward_fast_eligible(hr_rows, hr_cols, ch, scale, g))
     {
         const int w = hr_cols / 4, h = hr_rows / 4;
-        const int tiles_x = (w + 63) / 64, tiles_y = (h + 3) / 4;
-        const unsigned n_items = (unsigned)tiles_x * tiles_y * K;
-        const dim3 gr(xcd_grid(n_items)), b(256);
+        const int strips_x = (w + kFwdStrip - 1) / kFwdStrip;
+        const int row_groups = (h + kFwdRowsPerWave - 1) / kFwdRowsPerWave;
+        const unsigned n_items = (unsigned)strips_x * row_groups * K; // one wave each
+        const unsigned n_blocks = (n_items + 3) / 4;
+        const dim3 gr(xcd_grid(n_blocks)), b(256);
         if (ch == 1)
-            hipLaunchKernelGGL(k_forward_sign_s4<1>, gr, b, 0, st, X, hr_rows, hr_cols, *dec_bwd, raw_bwd, y, signs, K,
-                               g, tiles_x, n_items);
+            hipLaunchKernelGGL(k_forward_sign_s4<1>, gr, b, 0, st, X, hr_rows, hr_cols, *dec_bwd, y, signs, K, g,
+                               strips_x, n_items, n_blocks);
         else
-            hipLaunchKernelGGL(k_forward_sign_s4<3>, gr, b, 0, st, X, hr_rows, hr_cols, *dec_bwd, raw_bwd, y, signs, K,
-                               g, tiles_x, n_items);
+            hipLaunchKernelGGL(k_forward_sign_s4<3>, gr, b, 0, st, X, hr_rows, hr_cols, *dec_bwd, y, signs, K, g,
+                               strips_x, n_items, n_blocks);
         return check_launch("forward_sign_s4");
     }
     const dim3 b(64, 4);
@@ -942,6 +1024,7 @@ static bool make_fast_weights(const GaussK& g, FastW& fw)
     // per phase p = f & 3: slot A carries tap j = {0,-1,-2,+1}[p], slot B only exists for p == 2 (tap +2)
     const int gA[4] = {ki[0], ki[1], ki[2], ki[1]};
     const int gB[4] = {0, 0, ki[2], 0};
+    std::memset(&fw, 0, sizeof(fw));
     for (int py = 0; py < 4; ++py)
         for (int px = 0; px < 4; ++px)
         {
