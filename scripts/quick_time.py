@@ -16,12 +16,14 @@ ap.add_argument("--scale", type=int, default=4)
 ap.add_argument("--K", type=int, default=9)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--lam", type=float, default=0.03)
 a = ap.parse_args()
 
 lr, flows, _ = synth.make_sequence(a.K, a.rows, a.cols, a.ch, a.scale, seed=1234, device="cuda")
 y = [f.to(torch.float32) for f in lr]
 sr = api.BTV_L1()
 sr.set("scale", a.scale)
+sr.set("lambda", a.lam)
 for iters in (1, a.iters):
     sr.set("iterations", iters)
     ts = []

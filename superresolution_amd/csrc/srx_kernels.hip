@@ -648,8 +648,11 @@ __device__ __forceinline__ int key_sign(int a, int b)
 //    keys; sign(a-b) is a saturating subtract and a clamp; accumulation order is
 //    the reference's (lib/src/btv_l1.cpp:221-233).  NaN pixels are ordered as
 //    large values instead of comparing unordered.
+#ifndef SRX_B_WAVES
+#define SRX_B_WAVES 4
+#endif
 template <int CH>
-__global__ __launch_bounds__(256, 4) void k_backproject_update_s4(const float* __restrict__ X, float* __restrict__ X_out,
+__global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(const float* __restrict__ X, float* __restrict__ X_out,
                                                                 int H, int W, PtrList dec_fwd, PtrList raw_fwd,
                                                                 PtrList signs, int K, GaussK g, FastW fw, BtvW bw,
                                                                 double tau, double lambda, int tiles_x,
@@ -689,22 +692,36 @@ __global__ __launch_bounds__(256, 4) void k_backproject_update_s4(const float* _
         lutw[tid] = make_uint4(fw.w[tid][0], fw.w[tid][1], fw.w[tid][2], fw.w[tid][3]);
         luts[tid] = fw.wsum[tid];
     }
-    // ---- stage the X tile (as keys) in LDS
+    // ---- stage the X tile (as keys) in LDS; all loads are issued before the first is consumed
     {
         constexpr int V4 = LW * CH / 4; // float4 per row: 54 or 18
+        constexpr int NIT = (LROWS * V4 + 255) / 256;
         const int rowf = W * CH;
-        for (int idx = tid; idx < LROWS * V4; idx += 256)
+        float4 stage[NIT];
+        bool have[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
         {
+            const int idx = tid + it * 256;
             const int r = idx / V4, c4 = idx - r * V4;
             const int gi = i0 - HALO + r;
             const int f0 = (j0 - HL) * CH + 4 * c4;
-            v4i kv = {0, 0, 0, 0};
-            if (gi >= 0 && gi < H && f0 >= 0 && f0 + 3 < rowf)
+            have[it] = idx < LROWS * V4 && gi >= 0 && gi < H && f0 >= 0 && f0 + 3 < rowf;
+            stage[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (have[it])
+                stage[it] = *(const float4*)(X + (size_t)gi * rowf + f0);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+        {
+            const int idx = tid + it * 256;
+            const int r = idx / V4, c4 = idx - r * V4;
+            if (idx < LROWS * V4)
             {
-                const float4 v = *(const float4*)(X + (size_t)gi * rowf + f0);
-                kv = v4i{float_key(v.x), float_key(v.y), float_key(v.z), float_key(v.w)};
+                const float4 v = stage[it];
+                // outside the image the tile holds key(0); those cells are never read by an interior pixel
+                *(v4i*)&tile[r * PITCH + 4 * c4] = v4i{float_key(v.x), float_key(v.y), float_key(v.z), float_key(v.w)};
             }
-            *(v4i*)&tile[r * PITCH + 4 * c4] = kv;
         }
     }
     __syncthreads();
@@ -774,6 +791,11 @@ __global__ __launch_bounds__(256, 4) void k_backproject_update_s4(const float* _
         for (int c = 0; c < CH; ++c)
             acc[p][c] = 0;
     }
+#ifndef SRX_B_UNROLL
+#define SRX_B_UNROLL 1
+#endif
+    // the next frame's map entries are fetched while the current frame's sign cells are gathered
+#pragma unroll SRX_B_UNROLL
     for (int k = 0; k < K; ++k)
     {
         uint4 nxt = cur;
@@ -788,10 +810,11 @@ __global__ __launch_bounds__(256, 4) void k_backproject_update_s4(const float* _
             const uint32_t* s0 = sg + (e & kFwdCellMask);
             const uint32_t li = e >> kFwdLutShift;
             const uint4 wq = lutw[li];
-            uint32_t v = s0[0] * wq.x;
-            v += s0[1] * wq.y;
-            v += s0[w] * wq.z;
-            v += s0[w + 1] * wq.w;
+            // operands fit 24 bits: full-rate v_mad_u32_u24
+            uint32_t v = __umul24(s0[0], wq.x);
+            v += __umul24(s0[1], wq.y);
+            v += __umul24(s0[w], wq.z);
+            v += __umul24(s0[w + 1], wq.w);
             bias[p] += luts[li];
             slow |= (li == kFwdLutSlow) ? 1u : 0u;
 #pragma unroll
