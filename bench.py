@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Throughput of the BTV-L1 super-resolution hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = one steady-state SuperResolution::nextFrame() on one GPU: one new
+low-resolution frame enters the ring, its flow is attached, one output frame is
+solved (180 BTV-L1 iterations over a 2*4+1 frame window) and returned as 8-bit.
+Workload (BASELINE.json configs[3], the configuration the metric is quoted on):
+960x540 RGB -> 3840x2160, scale 4, temporalAreaRadius 4.  Inputs are synthetic
+(superresolution_amd/synth.py), 8-bit, resident in HBM before the timed region.
+
+Multi-GPU: the stream is cut into contiguous spans of output frames, one per
+rank (weak scaling: every rank solves `steps` frames); neighbouring ranks swap
+the temporalAreaRadius boundary frames point to point before the timed region.
+No collective sits on the data path.
+
+Prints one JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=540, help="LR rows")
+    ap.add_argument("--cols", type=int, default=960, help="LR cols")
+    ap.add_argument("--channels", type=int, default=3)
+    ap.add_argument("--scale", type=int, default=4)
+    ap.add_argument("--radius", type=int, default=4)
+    ap.add_argument("--iterations", type=int, default=180)
+    ap.add_argument("--flow", choices=["synthetic", "tvl1"], default="synthetic",
+                    help="motion stage: exact synthetic motion resident in HBM, or the built-in TV-L1 flow")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=20, help="iterations of the CPU sample solve")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(P, C, K, s):
+    """Compulsory-traffic model per solver iteration: X read + write, one int16x2 index per HR pixel and
+    map, one LR frame per window frame.  Split by kernel: forward = K * (4P + 4CP/s^2), back-projection +
+    update = 8CP + K * 4P."""
+    fwd = K * (4 * P + 4 * C * P / s ** 2)
+    bwd = 8 * C * P + K * 4 * P
+    return fwd, bwd
+
+
+def cpu_baseline(args, lr_u8, flows, base):
+    """The unfused restatement of the reference CPU path (oracle/, OpenMP over rows) on one window of the same
+    workload, for a bounded number of iterations; scaled to the full iteration count."""
+    import oracle
+
+    y = [f.cpu().numpy().astype(np.float32) for f in lr_u8]
+    fl = [f.cpu().numpy() for f in flows]
+    threads = oracle.max_threads()
+    times = {}
+    for it in (1, 1 + args.cpu_iters):
+        p = oracle.BtvParams(scale=args.scale, iterations=it)
+        t0 = time.perf_counter()
+        oracle.btvl1_process(y, fl, base, p)
+        times[it] = time.perf_counter() - t0
+    per_iter = (times[1 + args.cpu_iters] - times[1]) / args.cpu_iters
+    setup = max(times[1] - per_iter, 0.0)
+    frame_s = setup + per_iter * args.iterations
+    mpix = args.rows * args.cols * args.scale ** 2 / 1e6
+    return {
+        "value": mpix / frame_s,
+        "unit": "Mpix/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"one {len(y)}-frame window of the same workload, {1 + args.cpu_iters} solver iterations timed "
+                  f"({per_iter:.2f} s/iteration, {setup:.2f} s set-up), scaled to {args.iterations} iterations",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from superresolution_amd import api, spans, synth, _lib as L
+
+    r, s = args.radius, args.scale
+    # Calls: one set-up call (ring warm-up: 2r+2 reads), then W warm-up and K timed steady-state steps with one
+    # read, one flow and one solve each.  The solve of a call runs r+1 frames ahead of the output it returns, so
+    # a span of W + K + r + 2 owned frames keeps every timed solve inside the span with a full window.
+    n_own = args.warmup + args.steps + r + 2
+    total = n_own * world
+    a = rank * n_own
+    cams = synth.camera_path(total + 2 * r + 2, seed=1234)
+
+    def frame(t):
+        hr = synth.ground_truth_frame(cams[t], args.rows * s, args.cols * s, args.channels, 1234, dev)
+        return synth.degrade(hr, s)
+
+    own = [frame(t) for t in range(a, a + n_own)]
+    if world > 1:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        left, right = spans.exchange_halo(own, r, rank, world)
+        torch.cuda.synchronize()
+        halo_ms = (time.perf_counter() - t0) * 1e3
+    else:
+        left, right, halo_ms = [], [], 0.0
+    if rank == world - 1:
+        # the stream continues past the benchmarked frames, so that every timed step sees a full window
+        right = [frame(t) for t in range(a + n_own, a + n_own + r)]
+    first = a - len(left)
+    frames = left + own + right
+    flows = [synth.true_forward_flow(cams[first + i], cams[first + i + 1], args.rows, args.cols, s, dev)
+             for i in range(len(frames) - 1)]
+
+    sr = api.BTV_L1(local_rank)
+    sr.set("scale", s)
+    sr.set("iterations", args.iterations)
+    sr.set("temporalAreaRadius", r)
+    sr.set("outputMemory", L.SRX_MEM_DEVICE)
+    if args.flow == "tvl1":
+        sr.setOpticalFlow(api.DualTVL1())
+    else:
+        counter = {"i": 0}
+
+        def flow_cb(_f0, _f1):
+            f = flows[counter["i"]]
+            counter["i"] += 1
+            return f
+
+        sr.setOpticalFlow(flow_cb)
+    spans.configure_span(sr, left, own, right)
+
+    def step():
+        out = sr.nextFrame()
+        if out is None:
+            raise RuntimeError("stream ended inside the benchmark")
+        return out
+
+    step()  # ring warm-up: 2r+2 reads and the first solves (not a steady-state step)
+    for _ in range(args.warmup):
+        step()
+    sr.set("kernelTiming", 1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sr.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    fwd_ms, bwd_ms, n_it = sr.kernelTimes()
+    sr.set("kernelTiming", 0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        P = args.rows * s * args.cols * s
+        K = 2 * r + 1
+        mpix = P / 1e6
+        bytes_fwd, bytes_bwd = algorithmic_bytes(P, args.channels, K, s)
+        bwd_launch_s = bwd_ms / max(n_it, 1) / 1e3
+        fwd_launch_s = fwd_ms / max(n_it, 1) / 1e3
+        achieved = bytes_bwd / bwd_launch_s / 1e9
+        line = {
+            "metric": "output Mpix/s, BTV-L1 4x 960x540->4K, 1/2/4/8 GPUs; % HBM roofline",
+            "value": world * args.steps * mpix / elapsed,
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"configs[3]: {args.cols}x{args.rows} {'RGB' if args.channels == 3 else 'gray'} -> "
+                            f"{args.cols * s}x{args.rows * s}, {s}x BTV-L1, {args.iterations} iterations, "
+                            f"temporalAreaRadius {r} (window {K}), streaming nextFrame(), motion: "
+                            + ("built-in TV-L1 flow" if args.flow == "tvl1" else "exact synthetic flow resident in HBM"),
+                "frames_per_gpu": args.steps,
+                "partition": "contiguous span of output frames per GPU, halo of r LR frames swapped point to point",
+                "halo_exchange_ms": round(halo_ms, 3),
+                "delivered_frame": f"{args.cols * s - 14}x{args.rows * s - 14} (cropped by btvKernelSize)",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_backproject_update_s4 (back-projection of all window frames + BTV + update)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": bytes_bwd,
+                "avg_launch_us": bwd_launch_s * 1e6,
+                "forward_kernel": {"algorithmic_bytes_per_launch": bytes_fwd, "avg_launch_us": fwd_launch_s * 1e6,
+                                   "achieved": bytes_fwd / fwd_launch_s / 1e9},
+                "iteration": {"algorithmic_bytes": bytes_fwd + bytes_bwd,
+                              "achieved": (bytes_fwd + bytes_bwd) / (fwd_launch_s + bwd_launch_s) / 1e9,
+                              "frac": (bytes_fwd + bytes_bwd) / (fwd_launch_s + bwd_launch_s) / 1e9 / HBM_PEAK_GBS},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base = min(r, len(frames) - 1)
+            win = frames[:2 * r + 1]
+            line["cpu_baseline"] = cpu_baseline(args, win, flows[:2 * r], base)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

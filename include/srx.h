@@ -94,7 +94,7 @@ SRX_API const char* srx_last_error(void);
 /* names and types as registered at lib/src/super_resolution.cpp:83-93:
  * scale, iterations, btvKernelSize, blurKernelSize, temporalAreaRadius (int);
  * tau, lambda, alpha, blurSigma (double).  Extra int names of this library:
- * outputMemory (SRX_MEM_*; default host), traceEvents (0/1). */
+ * outputMemory (SRX_MEM_*; default host), traceEvents (0/1), kernelTiming (0/1). */
 SRX_API int srx_set_int(srx_handle* h, const char* name, int value);
 SRX_API int srx_set_double(srx_handle* h, const char* name, double value);
 SRX_API int srx_get_int(srx_handle* h, const char* name, int* value);
@@ -233,6 +233,13 @@ SRX_API int srx_run(srx_handle* h, const float* const* y_host, const float* cons
 /* same, from n-1 consecutive forward motions: lib/src/btv_l1.cpp:328-355 */
 SRX_API int srx_process_device(srx_handle* h, const float* const* y_host, const float* const* fwd_motions_host, int K,
                                int base_idx, int rows, int cols, int ch, float* out, float* x_full);
+/* Per-kernel timing of the solver loop, measured with HIP events on the
+ * handle's stream while the int parameter "kernelTiming" is 1 (setting it also
+ * clears the totals): summed durations of the forward (sign) and
+ * back-projection/update launches and the number of iterations they cover.
+ * Synchronises the stream.  No counterpart in the reference (its samples time
+ * whole frames, samples/video/main.cpp:40-47). */
+SRX_API int srx_kernel_times(srx_handle* h, double* forward_ms, double* backproject_ms, long* iterations);
 /* Stream the handle launches on (hipStream_t), for callers that time or order work against it. */
 SRX_API void* srx_stream(srx_handle* h);
 /* Blocks until everything queued on the handle's stream has finished. */

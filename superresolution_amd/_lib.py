@@ -82,6 +82,7 @@ SIGNATURES = {
     "srx_process_device": (C.c_int, [_vp, _vpp, _vpp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "srx_set_kernel_path": (C.c_int, [C.c_int]),
     "srx_get_kernel_path": (C.c_int, []),
+    "srx_kernel_times": (C.c_int, [_vp, _dp, _dp, C.POINTER(C.c_long)]),
     "srx_stream": (_vp, [_vp]),
     "srx_synchronize": (C.c_int, [_vp]),
 }

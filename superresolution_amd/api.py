@@ -19,7 +19,7 @@ import numpy as np
 from . import _lib as L
 
 _INT_PARAMS = ("scale", "iterations", "btvKernelSize", "blurKernelSize", "temporalAreaRadius", "outputMemory",
-               "traceEvents")
+               "traceEvents", "kernelTiming")
 _DOUBLE_PARAMS = ("tau", "lambda", "alpha", "blurSigma")
 
 
@@ -287,6 +287,12 @@ class BTV_L1:
 
     def synchronize(self):
         L.check(self._lib.srx_synchronize(self._h))
+
+    def kernelTimes(self):
+        """(forward_ms, backproject_ms, iterations) summed since kernelTiming was last set."""
+        f, b, n = C.c_double(), C.c_double(), C.c_long()
+        L.check(self._lib.srx_kernel_times(self._h, C.byref(f), C.byref(b), C.byref(n)))
+        return f.value, b.value, n.value
 
     @property
     def handle(self):

@@ -450,6 +450,12 @@ SRX_API int srx_set_int(srx_handle* h, const char* name, int value)
         h->trace = value != 0;
         return SRX_OK;
     }
+    if (n == "kernelTiming")
+    {
+        h->solver.enable_timing(value != 0);
+        h->solver.reset_timing();
+        return SRX_OK;
+    }
     if (int* p = int_param(h, n))
     {
         Params trial = h->p;
@@ -509,6 +515,11 @@ SRX_API int srx_get_int(srx_handle* h, const char* name, int* value)
     if (n == "traceEvents")
     {
         *value = h->trace;
+        return SRX_OK;
+    }
+    if (n == "kernelTiming")
+    {
+        *value = h->solver.timing();
         return SRX_OK;
     }
     if (int* p = int_param(h, n))
@@ -860,6 +871,27 @@ SRX_API int srx_collect_garbage(srx_handle* h)
     h->batch_out.release();
     h->batch_frames.clear();
     h->batch_motions.clear();
+    return SRX_OK;
+}
+
+SRX_API int srx_kernel_times(srx_handle* h, double* forward_ms, double* backproject_ms, long* iterations)
+{
+    SRX_NEED(h);
+    if (h->dry)
+    {
+        set_error("srx_kernel_times needs a GPU handle");
+        return SRX_ERR_STATE;
+    }
+    if (int rc = h->set_device())
+        return rc;
+    if (int rc = h->solver.collect_timing(h->stream))
+        return rc;
+    if (forward_ms)
+        *forward_ms = h->solver.fwd_ms();
+    if (backproject_ms)
+        *backproject_ms = h->solver.bwd_ms();
+    if (iterations)
+        *iterations = h->solver.timed_iterations();
     return SRX_OK;
 }
 

@@ -103,6 +103,10 @@ class CubicTablesDev
 class Solver
 {
   public:
+    Solver() = default;
+    Solver(const Solver&) = delete;
+    Solver& operator=(const Solver&) = delete;
+    ~Solver() { release(); }
     int run(const float* const* y, const float* const* rel, int K, int base_idx, int rows, int cols, int ch,
             const Params& p, float* out, float* x_full, hipStream_t st);
     int process(const float* const* y, const float* const* fwd_motions, int K, int base_idx, int rows, int cols,
@@ -110,6 +114,17 @@ class Solver
     // HR image after the last run (device), rows*scale x cols*scale x ch
     const float* last_x() const { return x_[cur_].as<float>(); }
     void release();
+
+    // Optional per-kernel timing with HIP events on the solver's stream: every
+    // iteration's forward and back-projection launches are bracketed by events
+    // that are read back (after a stream synchronise) by collect_timing().
+    void enable_timing(bool on) { timing_ = on; }
+    bool timing() const { return timing_; }
+    int collect_timing(hipStream_t st);
+    void reset_timing() { fwd_ms_ = bwd_ms_ = 0.0, timed_iters_ = 0; }
+    double fwd_ms() const { return fwd_ms_; }
+    double bwd_ms() const { return bwd_ms_; }
+    long timed_iterations() const { return timed_iters_; }
 
   private:
     int ensure(int K, int rows, int cols, int ch, int scale, hipStream_t st);
@@ -124,6 +139,11 @@ class Solver
     BtvW btv_{};
     int curBtvKernelSize_ = -1;
     double curAlpha_ = -1.0;
+    bool timing_ = false;
+    std::vector<hipEvent_t> events_; // 3 per iteration of the last run
+    int pending_iters_ = 0;
+    double fwd_ms_ = 0.0, bwd_ms_ = 0.0;
+    long timed_iters_ = 0;
 };
 
 } // namespace srx

@@ -265,8 +265,30 @@ int Solver::ensure(int K, int rows, int cols, int ch, int scale, hipStream_t st)
     return tables_.ensure(rows, cols, rows * scale, cols * scale, st);
 }
 
+int Solver::collect_timing(hipStream_t st)
+{
+    if (pending_iters_ == 0)
+        return SRX_OK;
+    SRX_HIP(hipStreamSynchronize(st));
+    for (int it = 0; it < pending_iters_; ++it)
+    {
+        float a = 0.f, b = 0.f;
+        SRX_HIP(hipEventElapsedTime(&a, events_[3 * it], events_[3 * it + 1]));
+        SRX_HIP(hipEventElapsedTime(&b, events_[3 * it + 1], events_[3 * it + 2]));
+        fwd_ms_ += a;
+        bwd_ms_ += b;
+    }
+    timed_iters_ += pending_iters_;
+    pending_iters_ = 0;
+    return SRX_OK;
+}
+
 void Solver::release()
 {
+    for (hipEvent_t e : events_)
+        (void)hipEventDestroy(e);
+    events_.clear();
+    pending_iters_ = 0;
     fwd_maps_.clear();
     bwd_maps_.clear();
     dec_fwd_.clear();
@@ -352,17 +374,36 @@ int Solver::run(const float* const* y, const float* const* rel, int K, int base_
     if (int rc = launch_resize_cubic(y[base_idx], rows, cols, ch, t, x_[0].as<float>(), (int)R, (int)C, st))
         return rc;
 
+    if (timing_)
+    {
+        if (int rc = collect_timing(st)) // events of the previous run are about to be re-recorded
+            return rc;
+        while ((int)events_.size() < 3 * p.iterations)
+        {
+            hipEvent_t e;
+            SRX_HIP(hipEventCreate(&e));
+            events_.push_back(e);
+        }
+    }
     for (int it = 0; it < p.iterations; ++it)
     {
+        if (timing_)
+            SRX_HIP(hipEventRecord(events_[3 * it], st));
         if (int rc = launch_forward_sign(x_[cur_].as<float>(), (int)R, (int)C, ch, bwd, fastA ? &dbwd : nullptr, ys,
                                          sgm, K, s, gauss_, st))
             return rc;
+        if (timing_)
+            SRX_HIP(hipEventRecord(events_[3 * it + 1], st));
         if (int rc = launch_backproject_update(x_[cur_].as<float>(), x_[cur_ ^ 1].as<float>(), (int)R, (int)C, ch,
                                                fwd, fastB ? &dfwd : nullptr, sg, K, s, gauss_, btv_, p.tau, p.lambda,
                                                st))
             return rc;
+        if (timing_)
+            SRX_HIP(hipEventRecord(events_[3 * it + 2], st));
         cur_ ^= 1;
     }
+    if (timing_)
+        pending_iters_ = p.iterations;
 
     if (out)
         if (int rc = launch_crop_convert(x_[cur_].as<float>(), (int)R, (int)C, ch, B, out, SRX_32F, st))
