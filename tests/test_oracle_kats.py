@@ -1,0 +1,308 @@
+"""Known-answer tests of the CPU oracle, derived by hand from the reference source
+(lib/src/btv_l1.cpp, lib/src/ring_buffer.hpp) and from the OpenCV 2.4 semantics it relies on.
+
+The oracle is a restatement; the reference ships no tests or fixtures and cannot be built here (OpenCV is
+absent), so oracle-vs-reference parity is unpinned.  These tests pin the oracle to everything that can be
+derived on paper, and to independent numpy re-implementations of the two trickiest primitives.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import stream as ostream
+
+
+# K1: calcBtvWeights(7, 0.7) enumerates m = 0..3, l = 3 down to -m: 22 values alpha^(|m|+|l|)
+def test_btv_weights_enumeration():
+    w = oracle.calc_btv_weights(7, 0.7)
+    exps = [3, 2, 1, 0, 4, 3, 2, 1, 2, 5, 4, 3, 2, 3, 4, 6, 5, 4, 3, 4, 5, 6]
+    assert len(w) == 22
+    a = np.float32(0.7)
+    assert np.array_equal(w, np.array([np.float32(float(a) ** e) for e in exps], np.float32))
+    # other sizes: count = sum_{m=0..p} (p + m + 1)
+    for B, n in [(1, 1), (3, 5), (5, 12), (9, 35), (4, 5), (15, 92)]:
+        assert len(oracle.calc_btv_weights(B, 0.7)) == n
+
+
+# K2: constant image -> 0 everywhere; border band of width p stays 0 for any image
+def test_btv_constant_and_border(rng):
+    w = oracle.calc_btv_weights(7, 0.7)
+    assert not oracle.btv_regularization(np.full((20, 24), 3.5, np.float32), 7, w).any()
+    r = oracle.btv_regularization(rng.random((20, 24, 3)).astype(np.float32), 7, w)
+    assert not r[:3].any() and not r[-3:].any() and not r[:, :3].any() and not r[:, -3:].any()
+    assert r[3:-3, 3:-3].any()
+
+
+# K3: unit impulse: at the centre every pair contributes w * (1 - (-1)) except (0,0); at c - (l,m) and c + (l,m)
+# the value is -w(l,m) (summed where two enumerated pairs hit the same pixel)
+def test_btv_impulse():
+    n = 21
+    img = np.zeros((n, n), np.float32)
+    c = n // 2
+    img[c, c] = 1.0
+    w = oracle.calc_btv_weights(7, 0.7)
+    r = oracle.btv_regularization(img, 7, w)
+    pairs = [(l, m) for m in range(4) for l in range(3, -m - 1, -1)]
+    expect = np.zeros((n, n), np.float64)
+    acc_c = np.float32(0)
+    for (l, m), wt in zip(pairs, w):
+        if (l, m) != (0, 0):
+            acc_c = np.float32(acc_c + np.float32(wt * np.float32(2.0)))
+            expect[c - m, c - l] += -float(wt)  # pixel q = c - v sees the impulse at q + v
+            expect[c + m, c + l] += -float(wt)  # pixel q = c + v sees it at q - v
+    assert r[c, c] == acc_c
+    mask = np.ones((n, n), bool)
+    mask[c, c] = False
+    assert np.allclose(r[mask], expect[mask], rtol=0, atol=1e-6)
+    # truncated half plane: offsets (-2,1), (-3,1), (-3,2) are not enumerated, so those pixels stay 0
+    for l, m in [(-2, 1), (-3, 1), (-3, 2)]:
+        assert r[c + m, c + l] == 0 and r[c - m, c - l] == 0
+
+
+# K4: diffSign truth table including equality and NaN
+def test_diff_sign_truth_table():
+    a = np.array([2, 1, 1, np.nan, 1, -0.0, np.inf, -np.inf], np.float32)
+    b = np.array([1, 2, 1, 1, np.nan, 0.0, np.inf, np.inf], np.float32)
+    assert np.array_equal(oracle.diff_sign(a, b), np.array([1, -1, 0, 0, 0, 0, 0, -1], np.float32))
+
+
+# K5: zero-insert upscale: only (y*s, x*s) is non-zero
+def test_upscale_zero_insert(rng):
+    src = (rng.random((5, 7, 3)) + 1).astype(np.float32)
+    for s in (2, 3, 4):
+        up = oracle.upscale(src, s)
+        assert up.shape == (5 * s, 7 * s, 3)
+        assert np.array_equal(up[::s, ::s], src)
+        m = np.ones(up.shape[:2], bool)
+        m[::s, ::s] = False
+        assert not up[m].any()
+
+
+# K6: zero motion -> identity maps -> remap is a copy
+def test_zero_motion_identity(rng):
+    hr = oracle.upscale_motion(np.zeros((6, 8, 2), np.float32), 4)
+    assert not hr.any()
+    f, b = oracle.build_motion_maps(hr)
+    yy, xx = np.mgrid[0:24, 0:32]
+    assert np.array_equal(f[..., 0], xx) and np.array_equal(f[..., 1], yy) and np.array_equal(f, b)
+    img = rng.random((24, 32, 3)).astype(np.float32)
+    assert np.array_equal(oracle.remap_nearest(img, b), img)
+
+
+# K7: fixed point: lambda = 0, one frame, zero motion, y = D H X0 by the same ops -> X never moves
+def test_fixed_point(rng):
+    y0 = (rng.random((10, 12)) * 255).astype(np.float32)
+    p = oracle.BtvParams(iterations=5, lambda_=0.0)
+    X0 = oracle.resize_cubic(y0, 40, 48)
+    gk = oracle.gaussian_kernel(5, 0)
+    y = oracle.resize_nearest(oracle.sep_filter(X0, gk), 10, 12)
+    # run() starts from cubic(y), not X0; emulate one iteration from X0 with the stage functions
+    zero = np.zeros((10, 12, 2), np.float32)
+    f, b = oracle.build_motion_maps(oracle.upscale_motion(zero, 4))
+    c = oracle.resize_nearest(oracle.sep_filter(oracle.remap_nearest(X0, b), gk), 10, 12)
+    assert not oracle.diff_sign(y, c).any()
+
+
+# K8: window table for r = 4, last index 20 (lib/src/btv_l1.cpp:529-540)
+def test_window_table():
+    r = 4
+    for idx in range(5):  # warm-up: storePos = 2r
+        assert ostream.window(idx, r, 8) == (0, 8, idx)
+    assert ostream.window(5, r, 9) == (1, 9, 4)
+    assert ostream.window(16, r, 20) == (12, 20, 4)
+    assert ostream.window(18, r, 20) == (14, 20, 4)
+    assert ostream.window(20, r, 20) == (16, 20, 4)
+
+
+# K9: calcRelativeMotions with fwd = (1, 0), n = 5, base = 2 -> rel x = [2, 1, 0, -1, -2]
+def test_relative_motions_kat():
+    fwd = [np.zeros((3, 4, 2), np.float32) for _ in range(4)]
+    for f in fwd:
+        f[..., 0] = 1.0
+    rel = oracle.calc_relative_motions(fwd, 2, 3, 4)
+    assert [float(r[0, 0, 0]) for r in rel] == [2, 1, 0, -1, -2]
+    assert all(not r[..., 1].any() for r in rel)
+
+
+# K10 / K12: output size (sW-2B) x (sH-2B); one-iteration step bound |dX| <= tau * (K + lambda * 2 * sum(w))
+def test_output_size_and_step_bound(rng):
+    K, rows, cols = 3, 10, 12
+    y = [(rng.random((rows, cols)) * 255).astype(np.float32) for _ in range(K)]
+    fl = [np.zeros((rows, cols, 2), np.float32) for _ in range(K - 1)]
+    p0 = oracle.BtvParams(iterations=1)
+    out, x1 = oracle.btvl1_process(y, fl, 1, p0, return_full=True)
+    assert out.shape == (rows * 4 - 14, cols * 4 - 14)
+    x0 = oracle.resize_cubic(y[1], rows * 4, cols * 4)
+    bound = p0.tau * (K + p0.lambda_ * 2 * float(oracle.calc_btv_weights(7, 0.7).sum()))
+    assert np.abs(x1 - x0).max() <= bound + 1e-4
+    assert np.array_equal(out, x1[7:-7, 7:-7])
+
+
+# K11: ring helper at(-1, size 9) -> slot 8
+def test_ring_wrap():
+    assert oracle.border_wrap(-1, 9) == 8
+    assert oracle.border_wrap(9, 9) == 0
+    assert oracle.border_wrap(-10, 9) == 8
+    assert [oracle.border_wrap(i, 9) for i in range(9)] == list(range(9))
+    assert [oracle.border_reflect101(i, 5) for i in (-2, -1, 0, 4, 5, 6)] == [2, 1, 0, 4, 3, 2]
+    assert oracle.border_reflect101(-7, 4) == 1 and oracle.border_reflect101(3, 1) == 0
+
+
+# Gaussian kernels: OpenCV's fixed tables for sigma <= 0 and n <= 7, formula otherwise
+def test_gaussian_kernel_tables():
+    assert np.array_equal(oracle.gaussian_kernel(1, 0), [1])
+    assert np.array_equal(oracle.gaussian_kernel(3, 0), [.25, .5, .25])
+    assert np.array_equal(oracle.gaussian_kernel(5, 0), [.0625, .25, .375, .25, .0625])
+    assert np.array_equal(oracle.gaussian_kernel(7, 0), [.03125, .109375, .21875, .28125, .21875, .109375, .03125])
+    k = oracle.gaussian_kernel(9, 0)  # sigma = 0.3 * ((9 - 1) / 2 - 1) + 0.8 = 1.7
+    x = np.arange(9) - 4.0
+    ref = np.exp(-0.5 * x * x / 1.7 ** 2).astype(np.float32)
+    ref = (ref * (1.0 / ref.astype(np.float64).sum())).astype(np.float32)
+    assert np.array_equal(k, ref)
+    assert abs(float(oracle.gaussian_kernel(5, 1.3).sum()) - 1) < 1e-6
+
+
+# --- independent numpy second opinions ---------------------------------------------------------------------
+def _np_cubic_coeffs(x):
+    x = np.float32(x)
+    A = np.float32(-0.75)
+    one = np.float32(1)
+    c0 = ((A * (x + one) - np.float32(5) * A) * (x + one) + np.float32(8) * A) * (x + one) - np.float32(4) * A
+    c1 = ((A + np.float32(2)) * x - (A + np.float32(3))) * x * x + one
+    c2 = ((A + np.float32(2)) * (one - x) - (A + np.float32(3))) * (one - x) * (one - x) + one
+    c3 = one - c0 - c1 - c2
+    return np.array([c0, c1, c2, c3], np.float32)
+
+
+def _np_resize_cubic(src, s):
+    """cv::resize(INTER_CUBIC) of OpenCV 2.4 for an integer upscale, written directly from the formulas."""
+    rows, cols = src.shape
+    R, C = rows * s, cols * s
+    hres = np.zeros((rows, C), np.float32)
+    for dx in range(C):
+        fx = np.float32((dx + 0.5) / s - 0.5)
+        sx = int(np.floor(fx))
+        fx = np.float32(fx - np.float32(sx))
+        if sx < 0:
+            fx, sx = np.float32(0), 0
+        if sx >= cols - 1:
+            fx, sx = np.float32(0), cols - 1
+        a = _np_cubic_coeffs(fx)
+        idx = np.clip(np.arange(sx - 1, sx + 3), 0, cols - 1)
+        t = src[:, idx[0]] * a[0] + src[:, idx[1]] * a[1]
+        t = t + src[:, idx[2]] * a[2]
+        t = t + src[:, idx[3]] * a[3]
+        hres[:, dx] = t
+    out = np.zeros((R, C), np.float32)
+    for dy in range(R):
+        fy = np.float32((dy + 0.5) / s - 0.5)
+        sy = int(np.floor(fy))
+        b = _np_cubic_coeffs(np.float32(fy - np.float32(sy)))
+        idx = np.clip(np.arange(sy - 1, sy + 3), 0, rows - 1)
+        t = hres[idx[0]] * b[0] + hres[idx[1]] * b[1]
+        t = t + hres[idx[2]] * b[2]
+        t = t + hres[idx[3]] * b[3]
+        out[dy] = t
+    return out
+
+
+@pytest.mark.parametrize("s", [2, 3, 4])
+def test_resize_cubic_second_opinion(rng, s):
+    src = (rng.random((9, 11)) * 255).astype(np.float32)
+    assert np.array_equal(oracle.resize_cubic(src, 9 * s, 11 * s), _np_resize_cubic(src, s))
+
+
+def test_resize_cubic_properties():
+    # a constant image stays constant up to rounding; first/last columns are plain copies (sx < 0 / sx >= cols-1 rule)
+    src = np.arange(30, dtype=np.float32).reshape(5, 6) ** 2
+    up = oracle.resize_cubic(src, 20, 24)
+    hres_first = oracle.resize_cubic(src, 5, 24)  # horizontal only
+    assert np.array_equal(hres_first[:, 0], src[:, 0]) and np.array_equal(hres_first[:, 1], src[:, 0])
+    assert np.array_equal(hres_first[:, -1], src[:, -1]) and np.array_equal(hres_first[:, -2], src[:, -1])
+    c = oracle.resize_cubic(np.full((5, 6), 7.0, np.float32), 20, 24)
+    assert np.abs(c - 7).max() < 1e-5
+    assert up.shape == (20, 24)
+
+
+def test_remap_rounding_second_opinion(rng):
+    """cv::remap(INTER_NEAREST): index = saturate_cast<short>(cvRound(v)), round half to even; outside -> 0."""
+    v = np.array([0.5, 1.5, 2.5, -0.5, -1.5, 3.4999, 3.5001, 1e9, -1e9, np.nan, 32767.5, -32768.5, 40000.0],
+                 np.float32)
+    got = oracle.map_to_short(v.reshape(1, -1, 1).repeat(2, axis=2))[0, :, 0]
+    ref = [0, 2, 2, 0, -2, 3, 4, 32767, -32768, -32768, 32767, -32768, 32767]
+    assert list(got) == ref
+    img = rng.random((6, 8)).astype(np.float32)
+    fmap = rng.uniform(-2, 9, (6, 8, 2)).astype(np.float32)
+    ix = np.rint(fmap[..., 0]).astype(int)
+    iy = np.rint(fmap[..., 1]).astype(int)
+    ok = (ix >= 0) & (ix < 8) & (iy >= 0) & (iy < 6)
+    ref_img = np.where(ok, img[np.clip(iy, 0, 5), np.clip(ix, 0, 7)], 0).astype(np.float32)
+    assert np.array_equal(oracle.remap_nearest(img, fmap), ref_img)
+
+
+def test_sep_filter_second_opinion(rng):
+    """Row pass then column pass, REFLECT_101, centre + symmetric pairs (n <= 5) or left-to-right rows (n >= 7)."""
+    img = (rng.random((9, 10)) * 255).astype(np.float32)
+    for n, sigma in [(5, 0.0), (3, 0.0), (7, 0.0), (5, 1.1)]:
+        k = oracle.gaussian_kernel(n, sigma)
+        h = n // 2
+        p = np.pad(img, ((0, 0), (h, h)), mode="reflect")
+        if n <= 5:
+            row = p[:, h:h + 10] * k[h]
+            for j in range(1, h + 1):
+                row = row + (p[:, h - j:h - j + 10] + p[:, h + j:h + j + 10]) * k[h + j]
+        else:
+            row = k[0] * p[:, 0:10]
+            for j in range(1, n):
+                row = row + k[j] * p[:, j:j + 10]
+        row = row.astype(np.float32)
+        q = np.pad(row, ((h, h), (0, 0)), mode="reflect")
+        col = q[h:h + 9] * k[h]
+        for j in range(1, h + 1):
+            col = col + (q[h - j:h - j + 9] + q[h + j:h + j + 9]) * k[h + j]
+        assert np.array_equal(oracle.sep_filter(img, k), col.astype(np.float32))
+
+
+def test_add_weighted_is_double_arithmetic():
+    a = np.array([1.0, 100.0, 3.0], np.float32)
+    b = np.array([1e-7, 0.3, 7.0], np.float32)
+    ref = (a.astype(np.float64) * 1.0 + b.astype(np.float64) * 1.3 + 0.0).astype(np.float32)
+    assert np.array_equal(oracle.add_weighted(a, 1.0, b, 1.3), ref)
+
+
+def test_convert_8u_rounding():
+    v = np.array([0.5, 1.5, 2.5, 254.5, 255.5, -3.0, 300.0, np.nan, 127.49, 127.51], np.float32)
+    assert list(oracle.convert_8u(v)) == [0, 2, 2, 254, 255, 0, 255, 0, 127, 128]
+
+
+def test_resize_nearest_picks_block_origin(rng):
+    img = rng.random((12, 16, 3)).astype(np.float32)
+    for s in (2, 4):
+        assert np.array_equal(oracle.resize_nearest(img, 12 // s, 16 // s), img[::s, ::s])
+    assert np.array_equal(oracle.resize_nearest(img[:9, :9], 3, 3), img[:9:3, :9:3])
+
+
+def test_streaming_driver_counts():
+    """First nextFrame: 2r+2 reads, 2r+1 flows, r+2 solves; later calls: one of each; one output per input frame."""
+    n, r = 9, 2
+    frames = [np.full((8, 8), i, np.uint8) for i in range(n)]
+    o = ostream.BTV_L1(lambda a, b: np.zeros((8, 8, 2), np.float32))
+    o.params = oracle.BtvParams(iterations=1)
+    o.temporalAreaRadius = r
+    o.setFrameSource(ostream.ListFrameSource(frames))
+    assert o.nextFrame() is not None
+    kinds = [e[0] for e in o.log]
+    assert kinds.count("read") == 2 * r + 2 and kinds.count("flow") == 2 * r + 1 and kinds.count("solve") == r + 2
+    o.log.clear()
+    assert o.nextFrame() is not None
+    assert [e[0] for e in o.log] == ["read", "flow", "solve", "out"]
+    outs = 2
+    while o.nextFrame() is not None:
+        outs += 1
+    assert outs == n
+    # too short a stream trips the warm-up assertion (lib/src/btv_l1.cpp:479)
+    o2 = ostream.BTV_L1(lambda a, b: np.zeros((8, 8, 2), np.float32))
+    o2.temporalAreaRadius = 4
+    o2.setFrameSource(ostream.ListFrameSource(frames[:5]))
+    with pytest.raises(RuntimeError):
+        o2.nextFrame()

@@ -1,0 +1,81 @@
+"""Two-process (gloo, CPU) test of the span partitioning: halo exchange between neighbouring ranks and the
+per-span bookkeeping.  The arithmetic needs a GPU, so the handles here are dry-run handles; the GPU variant
+(tests/test_gpu_spans.py) checks the pixels."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+N_PER_RANK, RADIUS = 7, 2
+
+
+def _frame(t):
+    g = np.random.default_rng(1000 + t)
+    return g.integers(0, 256, (6, 8, 3), dtype=np.uint8)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from superresolution_amd import _lib as L, api, spans
+
+        total = N_PER_RANK * world
+        a, b, i0, i1 = spans.span_plan(total, RADIUS, world, rank)
+        own = [torch.from_numpy(_frame(t)) for t in range(a, b + 1)]
+        left, right = spans.exchange_halo(own, RADIUS)
+        ok = len(left) == a - i0 and len(right) == i1 - b
+        for i, f in enumerate(left):
+            ok &= bool(np.array_equal(f.numpy(), _frame(i0 + i)))
+        for i, f in enumerate(right):
+            ok &= bool(np.array_equal(f.numpy(), _frame(b + 1 + i)))
+
+        sr = api.BTV_L1(-1)
+        sr.set("temporalAreaRadius", RADIUS)
+        sr.set("traceEvents", 1)
+        sr.setOpticalFlow(lambda x, y: np.zeros((6, 8, 2), np.float32))
+        spans.configure_span(sr, [f.numpy() for f in left], [f.numpy() for f in own], [f.numpy() for f in right])
+        outs = 0
+        while sr.nextFrame() is not None:
+            outs += 1
+        solves = [(e[1] + i0, e[2] + i0, e[3] + i0, e[4]) for e in sr.drainEvents() if e[0] == L.SRX_EV_SOLVE]
+        q.put((rank, ok, outs, solves))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_halo_exchange_and_span_windows():
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    total = N_PER_RANK * world
+    got = []
+    for rank, ok, outs, solves in res:
+        assert ok, f"rank {rank}: halo frames differ from the neighbour's"
+        assert outs == N_PER_RANK
+        got += solves
+    # union of the per-rank solves = the unpartitioned stream's solves (global window function)
+    from oracle import stream as ostream
+
+    want = []
+    for idx in range(total):
+        store = min(max(idx + RADIUS, 2 * RADIUS), total - 1)
+        start, end, base = ostream.window(idx, RADIUS, store)
+        want.append((idx, start, end, base))
+    assert sorted(got) == want
