@@ -1,0 +1,126 @@
+// Exercises the C++ facade (include/srx/superres.hpp) on a dry-run object: no GPU needed.
+// Built and run by tests/test_cpp_facade.py.
+#include <srx/superres.hpp>
+
+#include <cstdio>
+#include <cstdlib>
+
+#define REQUIRE(c)                                                                                                     \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (!(c))                                                                                                      \
+        {                                                                                                              \
+            std::fprintf(stderr, "%s:%d: requirement failed: %s\n", __FILE__, __LINE__, #c);                           \
+            std::exit(1);                                                                                              \
+        }                                                                                                              \
+    } while (0)
+
+using namespace srx;
+
+struct CountingSource : IFrameSource
+{
+    int n, pos = 0, resets = 0;
+    Mat frame;
+    explicit CountingSource(int n) : n(n), frame(6, 8, 3, SRX_8U) {}
+    void reset() override { pos = 0, ++resets; }
+    Mat nextFrame() override { return pos++ < n ? frame : Mat(); }
+};
+
+struct ExtSource : FrameSource
+{
+    int n, pos = 0;
+    Mat frame;
+    explicit ExtSource(int n) : n(n), frame(6, 8, 1, SRX_8U) {}
+    void nextFrame(Mat& f) override { f = pos++ < n ? frame : Mat(); }
+    void reset() override { pos = 0; }
+};
+
+struct ZeroFlow : DenseOpticalFlow
+{
+    int calls = 0;
+    void calc(const Mat& f0, const Mat& f1, Mat& flow1, Mat*) override
+    {
+        REQUIRE(f0.rows() == f1.rows() && f0.cols() == f1.cols());
+        flow1.create(f0.rows(), f0.cols(), 2, SRX_32F);
+        ++calls;
+    }
+};
+
+int main()
+{
+    REQUIRE(initModule_superres());
+    // reference spelling: new BTV_L1, set/getInt, setFrameSource, nextFrame (samples/quality_test/main.cpp:255-316)
+    BTV_L1 sr(-1);
+    REQUIRE(sr.getInt("scale") == 4 && sr.getInt("iterations") == 180 && sr.getInt("btvKernelSize") == 7);
+    REQUIRE(sr.getInt("blurKernelSize") == 5 && sr.getInt("temporalAreaRadius") == 4);
+    REQUIRE(sr.getDouble("tau") == 1.3 && sr.getDouble("lambda") == 0.03 && sr.getDouble("alpha") == 0.7);
+    REQUIRE(sr.getDouble("blurSigma") == 0.0);
+    sr.set("temporalAreaRadius", 2);
+    sr.set("iterations", 20);
+    auto flow = std::make_shared<ZeroFlow>();
+    sr.set("opticalFlow", Ptr<DenseOpticalFlow>(flow));
+    auto src = std::make_shared<CountingSource>(9);
+    sr.setFrameSource(src);
+    int outs = 0;
+    for (;;)
+    {
+        Mat f = sr.nextFrame();
+        if (f.empty())
+            break;
+        REQUIRE(f.rows() == 6 * 4 - 14 && f.cols() == 8 * 4 - 14 && f.channels() == 3 && f.depth() == SRX_8U);
+        ++outs;
+    }
+    REQUIRE(outs == 9);
+    REQUIRE(flow->calls == 8); // one flow per consecutive frame pair
+    sr.reset();
+    REQUIRE(src->resets == 1);
+    REQUIRE(!sr.nextFrame().empty());
+
+    // invalid parameters throw instead of the reference's release-mode undefined behaviour
+    bool threw = false;
+    try
+    {
+        sr.set("scale", 1);
+    }
+    catch (const Exception& e)
+    {
+        threw = e.code == SRX_ERR_INVALID;
+    }
+    REQUIRE(threw && sr.getInt("scale") == 4);
+
+    // a stream shorter than 2r+1 frames trips the warm-up assertion (lib/src/btv_l1.cpp:479)
+    threw = false;
+    BTV_L1 shortsr(-1);
+    shortsr.setOpticalFlow(flow);
+    shortsr.setFrameSource(std::make_shared<CountingSource>(5));
+    try
+    {
+        shortsr.nextFrame();
+    }
+    catch (const Exception& e)
+    {
+        threw = e.code == SRX_ERR_SOURCE;
+    }
+    REQUIRE(threw);
+
+    // upstream spelling: createSuperResolution_BTVL1, setInput, nextFrame(Mat&), typed accessors
+    Ptr<BTV_L1> up = createSuperResolution_BTVL1(-1);
+    up->setScale(2);
+    up->setTemporalAreaRadius(1);
+    up->setKernelSize(5);
+    up->setTau(1.0);
+    up->setLabmda(0.05);
+    REQUIRE(up->getScale() == 2 && up->getKernelSize() == 5 && up->getLambda() == 0.05 && up->getTau() == 1.0);
+    up->setOpticalFlow(std::make_shared<ZeroFlow>());
+    up->setInput(std::make_shared<ExtSource>(4));
+    Mat out;
+    int n = 0;
+    for (up->nextFrame(out); !out.empty(); up->nextFrame(out))
+    {
+        REQUIRE(out.rows() == 6 * 2 - 10 && out.cols() == 8 * 2 - 10 && out.channels() == 1);
+        ++n;
+    }
+    REQUIRE(n == 4);
+    std::puts("facade ok");
+    return 0;
+}
