@@ -145,6 +145,14 @@ SRX_API int srx_process(srx_handle* h, const srx_image* frames, int n, const srx
 SRX_API int srx_flow_calc(srx_handle* h, const srx_image* frame0, const srx_image* frame1, srx_image* flow1,
                           srx_image* flow2);
 SRX_API int srx_collect_garbage(srx_handle* h);
+/* The built-in TV-L1 flow on two device-resident grey float images (rows x
+ * cols, values 0..255) with the handle's flow parameters: flow = rows x cols
+ * x 2 interleaved, device.  executed_iterations (optional) receives the
+ * number of inner iterations that ran.  This is the standalone flow stage of
+ * the path (the reference reaches its flow only through
+ * DenseOpticalFlow::calc, lib/include/optical_flow.hpp:44). */
+SRX_API int srx_flow_calc_device(srx_handle* h, const float* gray0, const float* gray1, int rows, int cols,
+                                 float* flow, long long* executed_iterations);
 
 /* Event trace of the streaming driver (needs traceEvents = 1).  Each event is
  * 5 ints {type, a, b, c, d}: READ{got}, FLOW{i}, SOLVE{idx,start,end,base},

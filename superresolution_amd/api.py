@@ -72,6 +72,18 @@ class DenseOpticalFlow:
     def calc(self, frame0, frame1):
         raise NotImplementedError
 
+    def calcFlowDevice(self, gray0, gray1):
+        """Built-in TV-L1 on two CUDA float grey images; returns ((rows, cols, 2) CUDA tensor, executed iterations)."""
+        import torch
+
+        rows, cols = gray0.shape
+        flow = torch.empty((rows, cols, 2), dtype=torch.float32, device=gray0.device)
+        n = C.c_longlong()
+        torch.cuda.synchronize()
+        L.check(self._lib.srx_flow_calc_device(self._h, gray0.contiguous().data_ptr(), gray1.contiguous().data_ptr(),
+                                               rows, cols, flow.data_ptr(), C.byref(n)))
+        return flow, n.value
+
     def collectGarbage(self):
         pass
 
@@ -281,6 +293,18 @@ class BTV_L1:
         hf = _describe(fl, keep)
         L.check(self._lib.srx_flow_calc(self._h, C.byref(f0), C.byref(f1), C.byref(hf), None))
         return fl
+
+    def calcFlowDevice(self, gray0, gray1):
+        """Built-in TV-L1 on two CUDA float grey images; returns ((rows, cols, 2) CUDA tensor, executed iterations)."""
+        import torch
+
+        rows, cols = gray0.shape
+        flow = torch.empty((rows, cols, 2), dtype=torch.float32, device=gray0.device)
+        n = C.c_longlong()
+        torch.cuda.synchronize()
+        L.check(self._lib.srx_flow_calc_device(self._h, gray0.contiguous().data_ptr(), gray1.contiguous().data_ptr(),
+                                               rows, cols, flow.data_ptr(), C.byref(n)))
+        return flow, n.value
 
     def collectGarbage(self):
         L.check(self._lib.srx_collect_garbage(self._h))

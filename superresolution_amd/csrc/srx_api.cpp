@@ -857,6 +857,23 @@ SRX_API int srx_flow_calc(srx_handle* h, const srx_image* frame0, const srx_imag
     return SRX_OK;
 }
 
+SRX_API int srx_flow_calc_device(srx_handle* h, const float* gray0, const float* gray1, int rows, int cols,
+                                 float* flow, long long* executed_iterations)
+{
+    SRX_NEED(h);
+    if (h->dry || !gray0 || !gray1 || !flow)
+    {
+        set_error("srx_flow_calc_device: needs a GPU handle and non-NULL images");
+        return SRX_ERR_INVALID;
+    }
+    if (int rc = h->set_device())
+        return rc;
+    if (int rc = h->tvl1.calc_gray(gray0, gray1, rows, cols, h->flow_params, flow, executed_iterations, h->stream))
+        return rc;
+    SRX_HIP(hipStreamSynchronize(h->stream));
+    return SRX_OK;
+}
+
 SRX_API int srx_collect_garbage(srx_handle* h)
 {
     SRX_NEED(h);

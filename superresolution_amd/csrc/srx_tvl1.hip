@@ -1,6 +1,8 @@
 // Built-in TV-L1 dense optical flow for gfx950.
 #include "srx_tvl1.h"
 
+#include <algorithm>
+
 namespace srx
 {
 
@@ -102,20 +104,486 @@ int tvl1_get_double(const Tvl1Params& p, const std::string& n, double* v)
     return SRX_OK;
 }
 
-struct Tvl1::Impl
+// ---------------------------------------------------------------------------
+// Kernels.  Every float operation follows the order of the CPU statement of this flow
+// (oracle/tvl1_oracle.c in this repository's tests); the file is built with -ffp-contract=off.
+namespace
 {
-};
 
-int Tvl1::calc_images(const srx_image&, const srx_image&, const Tvl1Params&, float*, long long*, hipStream_t)
+__device__ __forceinline__ int reflect101(int p, int len)
 {
-    set_error("built-in TV-L1 flow is not available in this build");
-    return SRX_ERR_FLOW;
+    if ((unsigned)p < (unsigned)len)
+        return p;
+    if (len == 1)
+        return 0;
+    do
+    {
+        p = p < 0 ? -p : 2 * len - 2 - p;
+    } while ((unsigned)p >= (unsigned)len);
+    return p;
 }
 
-int Tvl1::calc_gray(const float*, const float*, int, int, const Tvl1Params&, float*, long long*, hipStream_t)
+// frame -> 8-bit grey as convertToType(frame, CV_8U, 1) does (lib/src/input_array_utility.cpp:77-124), as float
+__global__ void k_to_gray(const void* __restrict__ src, size_t count, int ch, int is_float, float* __restrict__ dst)
 {
-    set_error("built-in TV-L1 flow is not available in this build");
-    return SRX_ERR_FLOW;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count)
+        return;
+    int c[4] = {0, 0, 0, 0};
+    for (int k = 0; k < ch; ++k)
+    {
+        if (is_float)
+        {
+            const float v = ((const float*)src)[i * ch + k] * 255.0f;
+            float r = rintf(v);
+            r = r < 0.f ? 0.f : (r > 255.f ? 255.f : r);
+            c[k] = (v != v) ? 0 : (int)r;
+        }
+        else
+            c[k] = ((const uint8_t*)src)[i * ch + k];
+    }
+    dst[i] = ch == 1 ? (float)c[0] : (float)((c[0] * 1868 + c[1] * 9617 + c[2] * 4899 + 8192) >> 14);
+}
+
+// 5-tap binomial {1,4,6,4,1}, REFLECT_101, even samples
+__global__ void k_pyr_down(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst, int dr, int dc)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= dc || y >= dr)
+        return;
+    const int c0 = reflect101(2 * x - 2, cols), c1 = reflect101(2 * x - 1, cols), c2 = 2 * x;
+    const int c3 = reflect101(2 * x + 1, cols), c4 = reflect101(2 * x + 2, cols);
+    float r[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+    {
+        const float* S = src + (size_t)reflect101(2 * y - 2 + j, rows) * cols;
+        r[j] = S[c2] * 6 + (S[c1] + S[c3]) * 4 + S[c0] + S[c4];
+    }
+    dst[(size_t)y * dc + x] = (r[2] * 6 + (r[1] + r[3]) * 4 + r[0] + r[4]) * 0.00390625f;
+}
+
+__global__ void k_centered_gradient(const float* __restrict__ src, int rows, int cols, float* __restrict__ dx,
+                                    float* __restrict__ dy)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= cols || y >= rows)
+        return;
+    const int xm = x > 0 ? x - 1 : 0, xp = x < cols - 1 ? x + 1 : cols - 1;
+    const int ym = y > 0 ? y - 1 : 0, yp = y < rows - 1 ? y + 1 : rows - 1;
+    const size_t i = (size_t)y * cols + x;
+    dx[i] = 0.5f * (src[(size_t)y * cols + xp] - src[(size_t)y * cols + xm]);
+    dy[i] = 0.5f * (src[(size_t)yp * cols + x] - src[(size_t)ym * cols + x]);
+}
+
+__device__ __forceinline__ void cubic_coeffs(float x, float (&c)[4])
+{
+    const float A = -0.75f;
+    c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+// bicubic warp of I1, I1x, I1y by (u1, u2), zero outside; grad = |grad I1w|^2,
+// rho_c = I1w - I1wx*u1 - I1wy*u2 - I0
+__global__ void k_warp(const float* __restrict__ I0, const float* __restrict__ I1, const float* __restrict__ I1x,
+                       const float* __restrict__ I1y, const float* __restrict__ u1, const float* __restrict__ u2,
+                       int rows, int cols, float* __restrict__ I1wx, float* __restrict__ I1wy,
+                       float* __restrict__ grad, float* __restrict__ rho_c)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= cols || y >= rows)
+        return;
+    const size_t i = (size_t)y * cols + x;
+    const float a = u1[i], b = u2[i];
+    const float fx = (float)x + a, fy = (float)y + b;
+    float w = 0.f, wx = 0.f, wy = 0.f;
+    if (fabsf(fx) < 1e8f && fabsf(fy) < 1e8f)
+    {
+        const float flx = floorf(fx), fly = floorf(fy);
+        const int sx = (int)flx, sy = (int)fly;
+        float cx[4], cy[4];
+        cubic_coeffs(fx - flx, cx);
+        cubic_coeffs(fy - fly, cy);
+        float h0[4], h1[4], h2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+            const int yy = sy - 1 + j;
+            float t0[4], t1[4], t2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+            {
+                const int xx = sx - 1 + k;
+                const bool in = (unsigned)xx < (unsigned)cols && (unsigned)yy < (unsigned)rows;
+                const size_t o = in ? (size_t)yy * cols + xx : 0;
+                t0[k] = in ? I1[o] : 0.f;
+                t1[k] = in ? I1x[o] : 0.f;
+                t2[k] = in ? I1y[o] : 0.f;
+            }
+            h0[j] = t0[0] * cx[0] + t0[1] * cx[1] + t0[2] * cx[2] + t0[3] * cx[3];
+            h1[j] = t1[0] * cx[0] + t1[1] * cx[1] + t1[2] * cx[2] + t1[3] * cx[3];
+            h2[j] = t2[0] * cx[0] + t2[1] * cx[1] + t2[2] * cx[2] + t2[3] * cx[3];
+        }
+        w = h0[0] * cy[0] + h0[1] * cy[1] + h0[2] * cy[2] + h0[3] * cy[3];
+        wx = h1[0] * cy[0] + h1[1] * cy[1] + h1[2] * cy[2] + h1[3] * cy[3];
+        wy = h2[0] * cy[0] + h2[1] * cy[1] + h2[2] * cy[2] + h2[3] * cy[3];
+    }
+    I1wx[i] = wx;
+    I1wy[i] = wy;
+    grad[i] = wx * wx + wy * wy;
+    rho_c[i] = w - wx * a - wy * b - I0[i];
+}
+
+__device__ __forceinline__ unsigned long long error_term(float du1, float du2)
+{
+    float q = du1 * du1 + du2 * du2;
+    if (!(q < 4096.0f))
+        q = 4096.0f;
+    return (unsigned long long)(q * 1073741824.0f);
+}
+
+// Inner iteration, first half: thresholding step, divergence of p, primal update, error.
+// err[it] receives the iteration's fixed-point error (integer adds: order independent).
+// The iteration runs only if the previous one's error exceeded the threshold; err[] starts at zero,
+// so once one iteration has been skipped or has converged all later ones see "converged" too.
+__global__ __launch_bounds__(256) void k_tvl1_u(const float* __restrict__ I1wx, const float* __restrict__ I1wy,
+                                                 const float* __restrict__ grad, const float* __restrict__ rho_c,
+                                                 float* __restrict__ u1, float* __restrict__ u2,
+                                                 const float* __restrict__ p11, const float* __restrict__ p12,
+                                                 const float* __restrict__ p21, const float* __restrict__ p22, int rows,
+                                                 int cols, float l_t, float theta, unsigned long long* __restrict__ err,
+                                                 int it, unsigned long long thr)
+{
+    if (it > 0 && err[it - 1] <= thr)
+        return;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    unsigned long long e = 0;
+    if (x < cols && y < rows)
+    {
+        const size_t i = (size_t)y * cols + x;
+        const float gx = I1wx[i], gy = I1wy[i], g = grad[i], a = u1[i], b = u2[i];
+        const float rho = rho_c[i] + (gx * a + gy * b);
+        float d1 = 0.0f, d2 = 0.0f;
+        if (rho < -l_t * g)
+        {
+            d1 = l_t * gx;
+            d2 = l_t * gy;
+        }
+        else if (rho > l_t * g)
+        {
+            d1 = -l_t * gx;
+            d2 = -l_t * gy;
+        }
+        else if (g > 1.1920929e-07f)
+        {
+            const float fi = -rho / g;
+            d1 = fi * gx;
+            d2 = fi * gy;
+        }
+        const float v1 = a + d1, v2 = b + d2;
+        const float q11 = p11[i], q12 = p12[i], q21 = p21[i], q22 = p22[i];
+        const float div1 = (x > 0 ? q11 - p11[i - 1] : q11) + (y > 0 ? q12 - p12[i - cols] : q12);
+        const float div2 = (x > 0 ? q21 - p21[i - 1] : q21) + (y > 0 ? q22 - p22[i - cols] : q22);
+        const float n1 = v1 + theta * div1, n2 = v2 + theta * div2;
+        e = error_term(n1 - a, n2 - b);
+        u1[i] = n1;
+        u2[i] = n2;
+    }
+    // block reduction of the integer error, one atomic per block
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        e += __shfl_down(e, o, 64);
+    __shared__ unsigned long long part[4];
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    if ((tid & 63) == 0)
+        part[tid >> 6] = e;
+    __syncthreads();
+    if (tid == 0)
+        atomicAdd(&err[it], part[0] + part[1] + part[2] + part[3]);
+}
+
+// second half: forward gradient of u, dual update
+__global__ __launch_bounds__(256) void k_tvl1_p(const float* __restrict__ u1, const float* __restrict__ u2,
+                                                 float* __restrict__ p11, float* __restrict__ p12,
+                                                 float* __restrict__ p21, float* __restrict__ p22, int rows, int cols,
+                                                 float taut, const unsigned long long* __restrict__ err, int it,
+                                                 unsigned long long thr)
+{
+    if (it > 0 && err[it - 1] <= thr)
+        return;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= cols || y >= rows)
+        return;
+    const size_t i = (size_t)y * cols + x;
+    const float a = u1[i], b = u2[i];
+    const float u1x = x < cols - 1 ? u1[i + 1] - a : 0.0f, u1y = y < rows - 1 ? u1[i + cols] - a : 0.0f;
+    const float u2x = x < cols - 1 ? u2[i + 1] - b : 0.0f, u2y = y < rows - 1 ? u2[i + cols] - b : 0.0f;
+    const float g1 = sqrtf(u1x * u1x + u1y * u1y), g2 = sqrtf(u2x * u2x + u2y * u2y);
+    const float ng1 = 1.0f + taut * g1, ng2 = 1.0f + taut * g2;
+    p11[i] = (p11[i] + taut * u1x) / ng1;
+    p12[i] = (p12[i] + taut * u1y) / ng1;
+    p21[i] = (p21[i] + taut * u2x) / ng2;
+    p22[i] = (p22[i] + taut * u2y) / ng2;
+}
+
+// cv::resize(INTER_LINEAR) of the two flow planes to the next finer level, times 2
+__global__ void k_upsample_flow(const float* __restrict__ s1, const float* __restrict__ s2, int srows, int scols,
+                                float* __restrict__ d1, float* __restrict__ d2, int drows, int dcols)
+{
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int dy = blockIdx.y * blockDim.y + threadIdx.y;
+    if (dx >= dcols || dy >= drows)
+        return;
+    const double scx = 1.0 / ((double)dcols / scols), scy = 1.0 / ((double)drows / srows);
+    float fx = (float)((dx + 0.5) * scx - 0.5);
+    int sx = (int)floor((double)fx);
+    fx -= sx;
+    if (sx < 0)
+        fx = 0, sx = 0;
+    if (sx >= scols - 1)
+        fx = 0, sx = scols - 1;
+    float fy = (float)((dy + 0.5) * scy - 0.5);
+    const int sy = (int)floor((double)fy);
+    fy -= sy;
+    const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+    const int y0 = sy < 0 ? 0 : (sy > srows - 1 ? srows - 1 : sy);
+    const int y1 = sy + 1 < 0 ? 0 : (sy + 1 > srows - 1 ? srows - 1 : sy + 1);
+    const bool last = sx >= scols - 1;
+    const size_t o = (size_t)dy * dcols + dx;
+    {
+        const float* R0 = s1 + (size_t)y0 * scols;
+        const float* R1 = s1 + (size_t)y1 * scols;
+        const float h0 = last ? R0[scols - 1] : R0[sx] * a0 + R0[sx + 1] * a1;
+        const float h1 = last ? R1[scols - 1] : R1[sx] * a0 + R1[sx + 1] * a1;
+        d1[o] = (h0 * b0 + h1 * b1) * 2.0f;
+    }
+    {
+        const float* R0 = s2 + (size_t)y0 * scols;
+        const float* R1 = s2 + (size_t)y1 * scols;
+        const float h0 = last ? R0[scols - 1] : R0[sx] * a0 + R0[sx + 1] * a1;
+        const float h1 = last ? R1[scols - 1] : R1[sx] * a0 + R1[sx + 1] * a1;
+        d2[o] = (h0 * b0 + h1 * b1) * 2.0f;
+    }
+}
+
+__global__ void k_merge2(const float* __restrict__ u, const float* __restrict__ v, size_t count,
+                         float2* __restrict__ uv)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < count)
+        uv[e] = make_float2(u[e], v[e]);
+}
+
+inline dim3 grid2(int cols, int rows, dim3 b)
+{
+    return dim3((cols + b.x - 1) / b.x, (rows + b.y - 1) / b.y);
+}
+
+#define SRX_LAUNCH_CHECK(what)                                                                                         \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        const hipError_t e__ = hipGetLastError();                                                                      \
+        if (e__ != hipSuccess)                                                                                         \
+            return hip_fail(e__, what);                                                                                \
+    } while (0)
+
+constexpr int kMaxScales = 16;
+constexpr int kPollStride = 32; // inner iterations enqueued between two looks at the error
+
+} // namespace
+
+struct Tvl1::Impl
+{
+    struct Level
+    {
+        int rows = 0, cols = 0;
+        DeviceBuffer I0, I1, u1, u2;
+    };
+    Level lv[kMaxScales];
+    DeviceBuffer I1x, I1y, I1wx, I1wy, grad, rho_c, p, err, raw0, raw1;
+    PinnedBuffer host_err;
+};
+
+int Tvl1::calc_images(const srx_image& f0, const srx_image& f1, const Tvl1Params& p, float* flow_uv,
+                      long long* executed_iters, hipStream_t st)
+{
+    if (!impl_)
+        impl_ = std::make_shared<Impl>();
+    Impl& m = *impl_;
+    const int rows = f0.rows, cols = f0.cols, ch = f0.channels;
+    if (ch != 1 && ch != 3 && ch != 4)
+    {
+        set_error("flow input must have 1, 3 or 4 channels");
+        return SRX_ERR_INVALID;
+    }
+    const size_t px = (size_t)rows * cols;
+    const size_t esz = f0.depth == SRX_8U ? 1 : 4;
+    const size_t rowbytes = (size_t)cols * ch * esz;
+    if (int rc = m.lv[0].I0.reserve(px * sizeof(float)))
+        return rc;
+    if (int rc = m.lv[0].I1.reserve(px * sizeof(float)))
+        return rc;
+    const srx_image* fr[2] = {&f0, &f1};
+    DeviceBuffer* raw[2] = {&m.raw0, &m.raw1};
+    float* gray[2] = {m.lv[0].I0.as<float>(), m.lv[0].I1.as<float>()};
+    for (int i = 0; i < 2; ++i)
+    {
+        if (int rc = raw[i]->reserve(rowbytes * rows))
+            return rc;
+        const size_t step = fr[i]->step ? fr[i]->step : rowbytes;
+        SRX_HIP(hipMemcpy2DAsync(raw[i]->get(), rowbytes, fr[i]->data, step, rowbytes, rows,
+                                 fr[i]->mem == SRX_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_to_gray, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, st, raw[i]->get(), px, ch,
+                           f0.depth == SRX_32F ? 1 : 0, gray[i]);
+        SRX_LAUNCH_CHECK("to_gray");
+    }
+    return calc_gray(nullptr, nullptr, rows, cols, p, flow_uv, executed_iters, st);
+}
+
+// I0 / I1 == nullptr: the level-0 images are already in place (calc_images)
+int Tvl1::calc_gray(const float* I0, const float* I1, int rows, int cols, const Tvl1Params& p, float* flow_uv,
+                    long long* executed_iters, hipStream_t st)
+{
+    if (!impl_)
+        impl_ = std::make_shared<Impl>();
+    Impl& m = *impl_;
+    if (rows < 1 || cols < 1 || !flow_uv)
+    {
+        set_error("tvl1: bad arguments");
+        return SRX_ERR_INVALID;
+    }
+    const dim3 b2(64, 4);
+    int nscales = std::min(std::max(p.nscales, 1), kMaxScales);
+    m.lv[0].rows = rows, m.lv[0].cols = cols;
+    const size_t px0 = (size_t)rows * cols;
+    if (I0)
+    {
+        if (int rc = m.lv[0].I0.reserve(px0 * sizeof(float)))
+            return rc;
+        if (int rc = m.lv[0].I1.reserve(px0 * sizeof(float)))
+            return rc;
+        SRX_HIP(hipMemcpyAsync(m.lv[0].I0.get(), I0, px0 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        SRX_HIP(hipMemcpyAsync(m.lv[0].I1.get(), I1, px0 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    for (int s = 1; s < nscales; ++s)
+    {
+        const int r = (m.lv[s - 1].rows + 1) / 2, c = (m.lv[s - 1].cols + 1) / 2;
+        if (c < 16 || r < 16)
+        {
+            nscales = s;
+            break;
+        }
+        Impl::Level& L = m.lv[s];
+        L.rows = r, L.cols = c;
+        if (int rc = L.I0.reserve((size_t)r * c * sizeof(float)))
+            return rc;
+        if (int rc = L.I1.reserve((size_t)r * c * sizeof(float)))
+            return rc;
+        hipLaunchKernelGGL(k_pyr_down, grid2(c, r, b2), b2, 0, st, m.lv[s - 1].I0.as<float>(), m.lv[s - 1].rows,
+                           m.lv[s - 1].cols, L.I0.as<float>(), r, c);
+        hipLaunchKernelGGL(k_pyr_down, grid2(c, r, b2), b2, 0, st, m.lv[s - 1].I1.as<float>(), m.lv[s - 1].rows,
+                           m.lv[s - 1].cols, L.I1.as<float>(), r, c);
+        SRX_LAUNCH_CHECK("pyr_down");
+    }
+    for (int s = 0; s < nscales; ++s)
+    {
+        const size_t n = (size_t)m.lv[s].rows * m.lv[s].cols * sizeof(float);
+        if (int rc = m.lv[s].u1.reserve(n))
+            return rc;
+        if (int rc = m.lv[s].u2.reserve(n))
+            return rc;
+    }
+    for (DeviceBuffer* d : {&m.I1x, &m.I1y, &m.I1wx, &m.I1wy, &m.grad, &m.rho_c})
+        if (int rc = d->reserve(px0 * sizeof(float)))
+            return rc;
+    if (int rc = m.p.reserve(4 * px0 * sizeof(float)))
+        return rc;
+    const int iters = std::max(p.iterations, 1);
+    if (int rc = m.err.reserve((size_t)iters * sizeof(unsigned long long)))
+        return rc;
+    if (int rc = m.host_err.reserve((size_t)iters * sizeof(unsigned long long)))
+        return rc;
+    unsigned long long* herr = (unsigned long long*)m.host_err.get();
+
+    const float l_t = (float)(p.lambda * p.theta), taut = (float)(p.tau / p.theta), theta = (float)p.theta;
+    long long executed = 0;
+    {
+        const size_t n = (size_t)m.lv[nscales - 1].rows * m.lv[nscales - 1].cols * sizeof(float);
+        SRX_HIP(hipMemsetAsync(m.lv[nscales - 1].u1.get(), 0, n, st));
+        SRX_HIP(hipMemsetAsync(m.lv[nscales - 1].u2.get(), 0, n, st));
+    }
+    for (int s = nscales - 1; s >= 0; --s)
+    {
+        Impl::Level& L = m.lv[s];
+        const int R = L.rows, C = L.cols;
+        const size_t n = (size_t)R * C;
+        const dim3 g2 = grid2(C, R, b2);
+        float* p11 = m.p.as<float>();
+        float *p12 = p11 + n, *p21 = p11 + 2 * n, *p22 = p11 + 3 * n;
+        hipLaunchKernelGGL(k_centered_gradient, g2, b2, 0, st, L.I1.as<float>(), R, C, m.I1x.as<float>(),
+                           m.I1y.as<float>());
+        SRX_LAUNCH_CHECK("centered_gradient");
+        SRX_HIP(hipMemsetAsync(p11, 0, 4 * n * sizeof(float), st));
+        const float scaled_eps = (float)(p.epsilon * p.epsilon * (double)n);
+        const unsigned long long thr = (unsigned long long)((double)scaled_eps * 1073741824.0);
+        for (int w = 0; w < p.warps; ++w)
+        {
+            hipLaunchKernelGGL(k_warp, g2, b2, 0, st, L.I0.as<float>(), L.I1.as<float>(), m.I1x.as<float>(),
+                               m.I1y.as<float>(), L.u1.as<float>(), L.u2.as<float>(), R, C, m.I1wx.as<float>(),
+                               m.I1wy.as<float>(), m.grad.as<float>(), m.rho_c.as<float>());
+            SRX_LAUNCH_CHECK("warp");
+            SRX_HIP(hipMemsetAsync(m.err.get(), 0, (size_t)iters * sizeof(unsigned long long), st));
+            int done = iters; // iterations that ran
+            for (int it0 = 0; it0 < iters; it0 += kPollStride)
+            {
+                const int it1 = std::min(it0 + kPollStride, iters);
+                for (int it = it0; it < it1; ++it)
+                {
+                    hipLaunchKernelGGL(k_tvl1_u, g2, b2, 0, st, m.I1wx.as<float>(), m.I1wy.as<float>(),
+                                       m.grad.as<float>(), m.rho_c.as<float>(), L.u1.as<float>(), L.u2.as<float>(),
+                                       p11, p12, p21, p22, R, C, l_t, theta, m.err.as<unsigned long long>(), it, thr);
+                    hipLaunchKernelGGL(k_tvl1_p, g2, b2, 0, st, L.u1.as<float>(), L.u2.as<float>(), p11, p12, p21,
+                                       p22, R, C, taut, m.err.as<unsigned long long>(), it, thr);
+                }
+                SRX_LAUNCH_CHECK("tvl1 iteration");
+                // the queued kernels already stop by themselves on the device; looking at the error here only
+                // saves enqueueing launches that would return at once
+                SRX_HIP(hipMemcpyAsync(herr + it0, m.err.as<unsigned long long>() + it0,
+                                       (size_t)(it1 - it0) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+                SRX_HIP(hipStreamSynchronize(st));
+                bool stop = false;
+                for (int it = it0; it < it1 && !stop; ++it)
+                    if (herr[it] <= thr)
+                    {
+                        done = it + 1;
+                        stop = true;
+                    }
+                if (stop)
+                    break;
+            }
+            executed += done;
+        }
+        if (s > 0)
+        {
+            Impl::Level& F = m.lv[s - 1];
+            hipLaunchKernelGGL(k_upsample_flow, grid2(F.cols, F.rows, b2), b2, 0, st, L.u1.as<float>(),
+                               L.u2.as<float>(), R, C, F.u1.as<float>(), F.u2.as<float>(), F.rows, F.cols);
+            SRX_LAUNCH_CHECK("upsample_flow");
+        }
+    }
+    hipLaunchKernelGGL(k_merge2, dim3((unsigned)((px0 + 255) / 256)), dim3(256), 0, st, m.lv[0].u1.as<float>(),
+                       m.lv[0].u2.as<float>(), px0, (float2*)flow_uv);
+    SRX_LAUNCH_CHECK("merge2");
+    if (executed_iters)
+        *executed_iters = executed;
+    return SRX_OK;
 }
 
 void Tvl1::release()
