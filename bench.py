@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--scale", type=int, default=4)
     ap.add_argument("--radius", type=int, default=4)
     ap.add_argument("--iterations", type=int, default=180)
-    ap.add_argument("--flow", choices=["synthetic", "tvl1"], default="synthetic",
+    ap.add_argument("--flow", choices=["synthetic", "tvl1"], default="tvl1",
                     help="motion stage: exact synthetic motion resident in HBM, or the built-in TV-L1 flow")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=20, help="iterations of the CPU sample solve")
