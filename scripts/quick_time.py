@@ -40,3 +40,10 @@ P = a.rows * a.cols * a.scale ** 2
 bytes_iter = 8 * a.ch * P + a.K * (8 * P + 4 * a.ch * P / a.scale ** 2)
 print(f"per-iteration {per_iter*1e3:.3f} ms; algorithmic {bytes_iter/1e6:.1f} MB/iter -> {bytes_iter/per_iter/1e9:.1f} GB/s "
       f"({bytes_iter/per_iter/8e12*100:.1f}% of 8 TB/s); 180-iter frame est {per_iter*180*1e3:.1f} ms")
+# per-kernel times from HIP events on the solver's stream
+sr.set("kernelTiming", 1)
+sr.set("iterations", a.iters)
+ops.process_device(sr, y, flows, a.K // 2)
+f, b, n = sr.kernelTimes()
+print(f"kernels: forward {f/n*1e3:.1f} us, backproject {b/n*1e3:.1f} us per launch over {n} iterations "
+      f"[{os.environ.get('SRX_LIBRARY', 'default library')}]", flush=True)

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsrx.so")
+# SRX_LIBRARY selects another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("SRX_LIBRARY") or os.path.join(_HERE, "libsrx.so")
 
 SRX_OK = 0
 SRX_ERR_INVALID, SRX_ERR_STATE, SRX_ERR_DEVICE, SRX_ERR_SOURCE, SRX_ERR_FLOW = 1, 2, 3, 4, 5

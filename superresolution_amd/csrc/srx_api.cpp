@@ -264,7 +264,7 @@ int srx_handle::process_frame(int idx)
     DeviceBuffer& res = results[slot(idx)];
     if (int rc = res.reserve((size_t)(R - 2 * B) * (C - 2 * B) * ch))
         return rc;
-    return launch_crop_convert(solver.last_x(), R, C, ch, B, res.get(), SRX_8U, stream);
+    return launch_crop_convert(solver.last_x(), R, C, ch, B, res.get(), SRX_8U, solver.last_x_plane_stride(), stream);
 }
 
 // BTV_L1::initImpl, lib/src/btv_l1.cpp:466-488
@@ -779,7 +779,7 @@ SRX_API int srx_process(srx_handle* h, const srx_image* frames, int n, const srx
     if ((rc = h->batch_out.reserve(obytes)))
         return rc;
     if ((rc = launch_crop_convert(h->solver.last_x(), rows * s, cols * s, ch, B, h->batch_out.get(), f0.depth,
-                                  h->stream)))
+                                  h->solver.last_x_plane_stride(), h->stream)))
         return rc;
     if ((rc = copy_from_device(h->batch_out.get(), *out, h->stream)))
         return rc;
@@ -1037,7 +1037,7 @@ SRX_API int srx_k_resize_cubic(const float* src, int srows, int scols, int ch, f
     CubicTablesDev t;
     if (int rc = t.ensure(srows, scols, drows, dcols, (hipStream_t)stream))
         return rc;
-    if (int rc = launch_resize_cubic(src, srows, scols, ch, t.view(), dst, drows, dcols, (hipStream_t)stream))
+    if (int rc = launch_resize_cubic(src, srows, scols, ch, t.view(), dst, drows, dcols, 0, (hipStream_t)stream))
         return rc;
     SRX_HIP(hipStreamSynchronize((hipStream_t)stream));
     return SRX_OK;
@@ -1106,22 +1106,31 @@ SRX_API int srx_k_forward_sign(const float* X, int hr_rows, int hr_cols, int ch,
     maps.p[0] = bwd_map;
     ys.p[0] = y;
     sg.p[0] = sign_out;
-    if (g_kernel_path == 0 && forward_fast_eligible(hr_rows, hr_cols, ch, scale, g))
+    BtvW bw7;
+    float w7[kMaxBtvWeights] = {0};
+    make_btv(7, w7, bw7);
+    if (g_kernel_path == 0 && forward_fast_eligible(hr_rows, hr_cols, ch, scale, g) &&
+        backproject_fast_eligible(hr_rows, hr_cols, ch, scale, g, bw7))
     {
-        // the specialised kernel wants a decoded map and an X with a trailing zero pixel
-        const size_t px = (size_t)hr_rows * hr_cols;
-        DeviceBuffer xpad, dec;
-        if (int rc = xpad.reserve((px + 1) * ch * sizeof(float)))
+        // the specialised kernels want a decoded map and X planar with a zero pixel behind every plane
+        const size_t px = (size_t)hr_rows * hr_cols, ps = plane_stride_for(px);
+        DeviceBuffer xpl, dec, pairs;
+        if (int rc = xpl.reserve(ps * ch * sizeof(float)))
             return rc;
         if (int rc = dec.reserve(px * 4))
             return rc;
-        SRX_HIP(hipMemcpyAsync(xpad.get(), X, px * ch * sizeof(float), hipMemcpyDeviceToDevice, st));
-        SRX_HIP(hipMemsetAsync(xpad.as<float>() + px * ch, 0, ch * sizeof(float), st));
+        if (int rc = pairs.reserve(sign_pair_bytes(hr_rows / 4, hr_cols / 4)))
+            return rc;
+        sg.p[0] = pairs.get();
+        SRX_HIP(hipMemsetAsync(xpl.get(), 0, ps * ch * sizeof(float), st));
+        if (int rc = launch_relayout(X, xpl.as<float>(), px, ch, ps, true, st))
+            return rc;
         if (int rc = launch_decode_maps(nullptr, bwd_map, hr_rows, hr_cols, nullptr, dec.as<uint32_t>(), st))
             return rc;
         dmaps.p[0] = dec.get();
-        if (int rc = launch_forward_sign(xpad.as<float>(), hr_rows, hr_cols, ch, maps, &dmaps, ys, sg, 1, scale, g,
-                                         st))
+        if (int rc = launch_forward_sign(xpl.as<float>(), hr_rows, hr_cols, ch, maps, &dmaps, ys, sg, 1, scale, g, st))
+            return rc;
+        if (int rc = launch_sign_unpair(pairs.as<uint32_t>(), sign_out, hr_rows / 4, hr_cols / 4, st))
             return rc;
         SRX_HIP(hipStreamSynchronize(st)); // the temporaries die with this call
         return SRX_OK;
@@ -1154,29 +1163,39 @@ SRX_API int srx_k_backproject_update(const float* X, float* X_out, int hr_rows, 
         maps.p[k] = fwd_maps_host[k];
         sg.p[k] = signs_host[k];
     }
-    if (g_kernel_path == 0 && backproject_fast_eligible(hr_rows, hr_cols, ch, scale, g, bw))
+    if (g_kernel_path == 0 && backproject_fast_eligible(hr_rows, hr_cols, ch, scale, g, bw) &&
+        forward_fast_eligible(hr_rows, hr_cols, ch, scale, g))
     {
-        // the specialised kernel wants decoded maps and sign planes padded by one row and one word
-        const size_t px = (size_t)hr_rows * hr_cols;
-        const size_t lr = (size_t)(hr_rows / 4) * (hr_cols / 4);
-        const size_t padded = ((size_t)(hr_rows / 4 + 1) * (hr_cols / 4) + 1) * 4;
+        // the specialised kernels want decoded maps, pair planes of signs, and planar images
+        const size_t px = (size_t)hr_rows * hr_cols, ps = plane_stride_for(px);
+        const size_t padded = sign_pair_bytes(hr_rows / 4, hr_cols / 4);
         std::vector<DeviceBuffer> dec(K), spad(K);
+        DeviceBuffer xin, xout;
+        if (int rc = xin.reserve(ps * ch * sizeof(float)))
+            return rc;
+        if (int rc = xout.reserve(ps * ch * sizeof(float)))
+            return rc;
+        SRX_HIP(hipMemsetAsync(xin.get(), 0, ps * ch * sizeof(float), st));
+        if (int rc = launch_relayout(X, xin.as<float>(), px, ch, ps, true, st))
+            return rc;
         for (int k = 0; k < K; ++k)
         {
             if (int rc = dec[k].reserve(px * 4))
                 return rc;
             if (int rc = spad[k].reserve(padded))
                 return rc;
-            SRX_HIP(hipMemsetAsync(spad[k].get(), 0, padded, st));
-            SRX_HIP(hipMemcpyAsync(spad[k].get(), signs_host[k], lr * 4, hipMemcpyDeviceToDevice, st));
+            if (int rc = launch_sign_pairs(signs_host[k], spad[k].as<uint32_t>(), hr_rows / 4, hr_cols / 4, st))
+                return rc;
             if (int rc = launch_decode_maps(fwd_maps_host[k], nullptr, hr_rows, hr_cols, dec[k].as<uint32_t>(),
                                             nullptr, st))
                 return rc;
             dmaps.p[k] = dec[k].get();
             sg.p[k] = spad[k].get();
         }
-        if (int rc = launch_backproject_update(X, X_out, hr_rows, hr_cols, ch, maps, &dmaps, sg, K, scale, g, bw, tau,
-                                               lambda, st))
+        if (int rc = launch_backproject_update(xin.as<float>(), xout.as<float>(), hr_rows, hr_cols, ch, maps, &dmaps,
+                                               sg, K, scale, g, bw, tau, lambda, st))
+            return rc;
+        if (int rc = launch_relayout(xout.as<float>(), X_out, px, ch, ps, false, st))
             return rc;
         SRX_HIP(hipStreamSynchronize(st));
         return SRX_OK;
@@ -1210,7 +1229,7 @@ SRX_API int srx_k_crop_convert(const float* X, int rows, int cols, int ch, int b
         set_error("srx_k_crop_convert: bad arguments");
         return SRX_ERR_INVALID;
     }
-    return launch_crop_convert(X, rows, cols, ch, border, dst, depth, (hipStream_t)stream);
+    return launch_crop_convert(X, rows, cols, ch, border, dst, depth, 0, (hipStream_t)stream);
 }
 
 SRX_API int srx_run(srx_handle* h, const float* const* y_host, const float* const* rel_host, int K, int base_idx,

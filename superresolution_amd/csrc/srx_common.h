@@ -63,24 +63,41 @@ int launch_build_maps(const float* rel, int rows, int cols, int scale, const Cub
                       int16_t* bwd_map, uint32_t* dec_fwd, uint32_t* dec_bwd, hipStream_t st);
 int launch_decode_maps(const int16_t* fwd_map, const int16_t* bwd_map, int hr_rows, int hr_cols, uint32_t* dec_fwd,
                        uint32_t* dec_bwd, hipStream_t st);
+// plane_stride == 0: interleaved HR image; otherwise planar (plane c at c * plane_stride floats)
 int launch_resize_cubic(const float* src, int srows, int scols, int ch, const CubicTables& t, float* dst, int drows,
-                        int dcols, hipStream_t st);
+                        int dcols, size_t plane_stride, hipStream_t st);
+int launch_relayout(const float* src, float* dst, size_t pixels, int ch, size_t plane_stride, bool to_planar,
+                    hipStream_t st);
+inline size_t plane_stride_for(size_t pixels)
+{
+    return pixels + 4; // keeps planes 16-byte aligned and leaves room for the zero pixel at index `pixels`
+}
 int launch_btv_regularization(const float* src, int rows, int cols, int ch, const BtvW& w, float* dst, hipStream_t st);
 // Which parameter sets the specialised kernels cover.
 bool forward_fast_eligible(int hr_rows, int hr_cols, int ch, int scale, const GaussK& g);
 bool backproject_fast_eligible(int hr_rows, int hr_cols, int ch, int scale, const GaussK& g, const BtvW& w);
+// Sign planes: the generic kernels use one word per LR pixel, the specialised ones a pair
+// plane of two words per LR pixel, {S(y, x), S(y+1, x)}, plus one spare cell.
+inline size_t sign_pair_bytes(int lr_rows, int lr_cols)
+{
+    return ((size_t)lr_rows * lr_cols + 1) * 8;
+}
+int launch_sign_pairs(const uint32_t* plain, uint32_t* pairs, int lr_rows, int lr_cols, hipStream_t st);
+int launch_sign_unpair(const uint32_t* pairs, uint32_t* plain, int lr_rows, int lr_cols, hipStream_t st);
 // sign(y_k - D H M_k X) for K frames in one launch.  With dec_bwd (and an
-// eligible parameter set) the specialised kernel runs; it needs X to carry the
-// zero pixel at index hr_rows*hr_cols.
+// eligible parameter set) the specialised kernel runs; it wants X planar
+// (plane_stride_for) with the zero pixel at index hr_rows*hr_cols of every plane
+// and writes pair planes.
 int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const PtrList& raw_bwd,
                         const PtrList* dec_bwd, const PtrList& y, const MutPtrList& signs, int K, int scale,
                         const GaussK& g, hipStream_t st);
 // With dec_fwd (and an eligible parameter set) the specialised kernel runs; it
-// needs every sign buffer to hold (rows/4 + 1) * (cols/4) + 1 words.
+// wants X and X_out planar and the signs as pair planes (sign_pair_bytes).
 int launch_backproject_update(const float* X, float* X_out, int hr_rows, int hr_cols, int ch, const PtrList& raw_fwd,
                               const PtrList* dec_fwd, const PtrList& signs, int K, int scale, const GaussK& g,
                               const BtvW& w, double tau, double lambda, hipStream_t st);
-int launch_crop_convert(const float* X, int rows, int cols, int ch, int border, void* dst, int depth, hipStream_t st);
+int launch_crop_convert(const float* X, int rows, int cols, int ch, int border, void* dst, int depth,
+                        size_t plane_stride, hipStream_t st);
 int launch_convert_8u_to_32f(const uint8_t* src, size_t count, float* dst, hipStream_t st);
 
 } // namespace srx

@@ -111,8 +111,10 @@ class Solver
             const Params& p, float* out, float* x_full, hipStream_t st);
     int process(const float* const* y, const float* const* fwd_motions, int K, int base_idx, int rows, int cols,
                 int ch, const Params& p, float* out, float* x_full, hipStream_t st);
-    // HR image after the last run (device), rows*scale x cols*scale x ch
+    // HR image after the last run (device), rows*scale x cols*scale x ch; planar with this plane
+    // stride when last_x_plane_stride() != 0, interleaved otherwise
     const float* last_x() const { return x_[cur_].as<float>(); }
+    size_t last_x_plane_stride() const { return ps_; }
     void release();
 
     // Optional per-kernel timing with HIP events on the solver's stream: every
@@ -131,6 +133,7 @@ class Solver
     std::vector<DeviceBuffer> fwd_maps_, bwd_maps_, dec_fwd_, dec_bwd_, signs_, rel_;
     DeviceBuffer x_[2];
     int cur_ = 0;
+    size_t ps_ = 0; // plane stride of x_ (0: interleaved)
     CubicTablesDev tables_;
     // cached filter / weights, re-derived on parameter change (lib/src/btv_l1.cpp:392-405)
     GaussK gauss_{};

@@ -5,9 +5,13 @@
 // written, in the order of the OpenCV routines the reference calls.
 //
 // Data layout in HBM
-//   images        float32, channels interleaved, dense rows.  Solver-owned HR
-//                 images carry one extra all-zero pixel at index rows*cols
-//                 (the value of cv::remap's constant border).
+//   images        float32, dense rows.  At the C ABI and in the generic kernels
+//                 channels are interleaved.  The specialised kernels keep the
+//                 HR image planar: plane c starts at c * plane_stride floats,
+//                 plane_stride = rows*cols + 4, and element rows*cols of every
+//                 plane is an all-zero pixel (the value of cv::remap's constant
+//                 border).  Planar gathers of neighbouring lanes hit
+//                 consecutive addresses; the BTV tile needs no de-interleave.
 //   raw maps      int16 (x, y) per HR pixel: the source index that
 //                 cv::remap(INTER_NEAREST) derives from its float map.
 //   decoded maps  one uint32 per HR pixel, derived from the raw maps for the
@@ -15,8 +19,13 @@
 //                   backward: linear source pixel index, or rows*cols (the
 //                             zero pixel) when the source is outside;
 //                   forward:  see kFwd* below.
-//   signs         one uint32 per LR pixel and window frame: sign+1 (0,1,2) of
-//                 channel c in bits 10c..10c+1.
+//   signs         one uint32 word per LR pixel and window frame: sign+1 (0,1,2)
+//                 of channel c in bits 10c..10c+1.  Generic kernels keep a
+//                 plain plane of words.  The specialised kernels keep a "pair
+//                 plane": cell (y, x) is the two words {S(y, x), S(y+1, x)},
+//                 so that one 16-byte read at a cell returns the 2x2 block
+//                 {S(y,x), S(y+1,x), S(y,x+1), S(y+1,x+1)}; rows*cols + 1
+//                 cells.
 //
 // Two families of kernels compute the same values: generic ones (any scale,
 // blur size, BTV size) and specialised ones (scale 4, 5-tap blur, BTV 7).
@@ -32,15 +41,19 @@ namespace
 
 // forward decoded-map entry (scale 4, 5-tap blur): a target (fx, fy) touches at
 // most the 2x2 block of LR sign cells whose top-left cell is `cell`
-//   bits 0..23   cell index (row*w + col)
-//   bits 24..28  weight-table index: 0..15 = (fx & 3) | (fy & 3) << 2,
-//                16 = target outside the image (all weights 0),
-//                17 = target within 2 px of the image edge, where reflect101
-//                     comes into play (weights 0 here; evaluated generically)
+//   bits 0..23   byte offset of the cell in the pair plane: 8 * (row*w + col)
+//   bits 24..28  weight-table index px + 5*py, where px = fx & 3 (py likewise)
+//                is the phase of the target on the LR grid; phase 4 stands for
+//                fx = cols-2, whose tap at fx+2 falls on the reflected border
+//                (reflect101 lands on a zero of the zero-inserted image, so the
+//                tap drops out; the same holds for every tap reflected at the
+//                left and top edges, which therefore need no entries of their
+//                own); 25 = all weights 0 (target outside the image, or in the
+//                last column / row, whose only tap is a reflected one)
 constexpr uint32_t kFwdCellMask = 0x00FFFFFFu;
 constexpr int kFwdLutShift = 24;
-constexpr uint32_t kFwdLutOutside = 16, kFwdLutSlow = 17;
-constexpr int kFwdLutSize = 18;
+constexpr uint32_t kFwdLutZero = 25;
+constexpr int kFwdLutSize = 26;
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 // volatile LDS vector access keeps 16-byte ds_read_b128 from being split into narrower reads
@@ -143,13 +156,12 @@ __device__ __forceinline__ uint32_t decode_bwd(int bx, int by, int R, int C)
 }
 __device__ __forceinline__ uint32_t decode_fwd(int fx, int fy, int R, int C)
 {
-    if ((unsigned)fx >= (unsigned)C || (unsigned)fy >= (unsigned)R)
-        return kFwdLutOutside << kFwdLutShift;
-    if (fx < 2 || fx > C - 3 || fy < 2 || fy > R - 3)
-        return kFwdLutSlow << kFwdLutShift;
+    if ((unsigned)fx >= (unsigned)(C - 1) || (unsigned)fy >= (unsigned)(R - 1))
+        return kFwdLutZero << kFwdLutShift;
     const int px = fx & 3, py = fy & 3;
     const int col = (fx >> 2) + (px == 3), row = (fy >> 2) + (py == 3);
-    return (uint32_t)(row * (C >> 2) + col) | ((uint32_t)(px | (py << 2)) << kFwdLutShift);
+    const int pxi = fx == C - 2 ? 4 : px, pyi = fy == R - 2 ? 4 : py;
+    return (uint32_t)(row * (C >> 2) + col) * 8u | ((uint32_t)(pxi + 5 * pyi) << kFwdLutShift);
 }
 
 // upscaleMotions + buildMotionMaps + remap's float->short index conversion
@@ -194,9 +206,10 @@ __global__ void k_decode_maps(const short2* __restrict__ fwd_map, const short2* 
         dec_fwd[o] = decode_fwd(fwd_map[o].x, fwd_map[o].y, R, C);
 }
 
+// ps == 0: interleaved destination; otherwise planar with plane stride ps
 template <int CH>
 __global__ void k_resize_cubic(const float* __restrict__ src, int srows, int scols, CubicTables t,
-                               float* __restrict__ dst, int drows, int dcols)
+                               float* __restrict__ dst, int drows, int dcols, size_t ps)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -204,10 +217,28 @@ __global__ void k_resize_cubic(const float* __restrict__ src, int srows, int sco
         return;
     float v[CH];
     cubic_sample<CH>(src, srows, scols, t.xofs[x], t.alpha[x], t.yofs[y], t.beta[y], v);
-    float* D = dst + ((size_t)y * dcols + x) * CH;
+    const size_t o = (size_t)y * dcols + x;
 #pragma unroll
     for (int c = 0; c < CH; ++c)
-        D[c] = v[c];
+        dst[ps ? c * ps + o : o * CH + c] = v[c];
+}
+
+// interleaved <-> planar copies (stage-level entry points and x_full output)
+template <int CH>
+__global__ void k_relayout(const float* __restrict__ src, float* __restrict__ dst, size_t count, size_t ps,
+                           int to_planar)
+{
+    const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= count)
+        return;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+    {
+        if (to_planar)
+            dst[c * ps + o] = src[o * CH + c];
+        else
+            dst[o * CH + c] = src[c * ps + o];
+    }
 }
 
 // ===========================================================================
@@ -369,14 +400,15 @@ __global__ void k_forward_sign(const float* __restrict__ X, int H, int W, PtrLis
 // Transposed chain.  B(fy, fx) = gauss(zero_insert(sign))(fy, fx) evaluated
 // lazily: the zero-inserted image is non-zero only where both coordinates are
 // multiples of scale.
-template <int CH>
+// SS = words per cell: 1 for a plain plane, 2 for a pair plane
+template <int CH, int SS = 1>
 __device__ __forceinline__ void sign_at(const uint32_t* __restrict__ sg, int w, int scale, int Yr, int Xr,
                                         float (&o)[CH])
 {
     // caller guarantees Yr % scale == 0
     if (Xr % scale == 0)
     {
-        const uint32_t s = sg[(size_t)(Yr / scale) * w + (Xr / scale)];
+        const uint32_t s = sg[((size_t)(Yr / scale) * w + (Xr / scale)) * SS];
 #pragma unroll
         for (int c = 0; c < CH; ++c)
             o[c] = (float)((int)((s >> (10 * c)) & 3u) - 1);
@@ -389,7 +421,7 @@ __device__ __forceinline__ void sign_at(const uint32_t* __restrict__ sg, int w, 
     }
 }
 
-template <int CH>
+template <int CH, int SS = 1>
 __device__ __forceinline__ void upsampled_blur_row(const uint32_t* __restrict__ sg, int W, int scale, int Yr, int fx,
                                                    const GaussK& g, float (&r)[CH])
 {
@@ -405,14 +437,14 @@ __device__ __forceinline__ void upsampled_blur_row(const uint32_t* __restrict__ 
     float t[CH], u[CH];
     if (n <= 5)
     {
-        sign_at<CH>(sg, w, scale, Yr, fx, t);
+        sign_at<CH, SS>(sg, w, scale, Yr, fx, t);
 #pragma unroll
         for (int c = 0; c < CH; ++c)
             r[c] = t[c] * g.k[hh];
         for (int j = 1; j <= hh; ++j)
         {
-            sign_at<CH>(sg, w, scale, Yr, reflect101(fx - j, W), t);
-            sign_at<CH>(sg, w, scale, Yr, reflect101(fx + j, W), u);
+            sign_at<CH, SS>(sg, w, scale, Yr, reflect101(fx - j, W), t);
+            sign_at<CH, SS>(sg, w, scale, Yr, reflect101(fx + j, W), u);
 #pragma unroll
             for (int c = 0; c < CH; ++c)
                 r[c] += (t[c] + u[c]) * g.k[hh + j];
@@ -420,13 +452,13 @@ __device__ __forceinline__ void upsampled_blur_row(const uint32_t* __restrict__ 
     }
     else
     {
-        sign_at<CH>(sg, w, scale, Yr, reflect101(fx - hh, W), t);
+        sign_at<CH, SS>(sg, w, scale, Yr, reflect101(fx - hh, W), t);
 #pragma unroll
         for (int c = 0; c < CH; ++c)
             r[c] = g.k[0] * t[c];
         for (int j = 1; j < n; ++j)
         {
-            sign_at<CH>(sg, w, scale, Yr, reflect101(fx - hh + j, W), t);
+            sign_at<CH, SS>(sg, w, scale, Yr, reflect101(fx - hh + j, W), t);
 #pragma unroll
             for (int c = 0; c < CH; ++c)
                 r[c] += g.k[j] * t[c];
@@ -435,20 +467,20 @@ __device__ __forceinline__ void upsampled_blur_row(const uint32_t* __restrict__ 
 }
 
 // (M^T H^T D^T sign)(i, j) for one frame: gather at the forward-map target
-template <int CH>
+template <int CH, int SS = 1>
 __device__ __forceinline__ void backproject_generic(const uint32_t* __restrict__ sg, int H, int W, int scale, int fx,
                                                     int fy, const GaussK& g, float (&a)[CH])
 {
     const int hh = g.n >> 1;
     float ra[CH], rb[CH];
-    upsampled_blur_row<CH>(sg, W, scale, fy, fx, g, ra);
+    upsampled_blur_row<CH, SS>(sg, W, scale, fy, fx, g, ra);
 #pragma unroll
     for (int c = 0; c < CH; ++c)
         a[c] = ra[c] * g.k[hh];
     for (int t = 1; t <= hh; ++t)
     {
-        upsampled_blur_row<CH>(sg, W, scale, reflect101(fy - t, H), fx, g, ra);
-        upsampled_blur_row<CH>(sg, W, scale, reflect101(fy + t, H), fx, g, rb);
+        upsampled_blur_row<CH, SS>(sg, W, scale, reflect101(fy - t, H), fx, g, ra);
+        upsampled_blur_row<CH, SS>(sg, W, scale, reflect101(fy + t, H), fx, g, rb);
 #pragma unroll
         for (int c = 0; c < CH; ++c)
             a[c] += (ra[c] + rb[c]) * g.k[hh + t];
@@ -501,36 +533,50 @@ __global__ void k_backproject_update(const float* __restrict__ X, float* __restr
 // Specialised kernels: scale 4, 5-tap blur (and BTV kernel size 7 for the update)
 // ===========================================================================
 
-// value of lane-1 / lane+1 within the 16-lane DPP row (0 at the row's ends)
-__device__ __forceinline__ float dpp_from_left(float v)
+// value held by lane-1 of the wave (0 in lane 0)
+__device__ __forceinline__ float from_left_lane(float v)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111 /* row_shr:1 */, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float dpp_from_right(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x101 /* row_shl:1 */, 0xF, 0xF, true));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xF, 0xF, true));
 }
 
-// Forward chain sign(y_k - D H M_k X), one wave per (strip of 28 LR columns,
-// group of LR rows, window frame).
+// four floats at any 4-byte aligned address: one global_load_dwordx4
+struct __attribute__((packed, aligned(4))) float4_a4
+{
+    float x, y, z, w;
+};
+
+// Forward chain sign(y_k - D H M_k X), one wave per (strip of 63 LR columns,
+// group of LR rows, window frame).  X is planar.
 //
-// Lanes own HR columns, not LR pixels: lane p of a 16-lane DPP row holds the
-// warped pixels of two adjacent HR columns (E = even, O = odd register), so a
-// wave's map reads and X gathers run over consecutive addresses.  The 5-tap row
-// pass at the even column of every odd lane is
-//     E*k0 + (O[p-1] + O[p])*k1 + (E[p-1] + E[p+1])*k2
-// with the neighbours fetched by DPP row shifts; 7 LR pixels per DPP row, 28
-// per wave.  The wave walks down its LR rows keeping the five row-pass results
-// of the current LR row in registers (four new HR rows per LR row).
+// Lane l works on LR column x = x0 - 1 + l and holds, per HR row and plane, the
+// warped pixels of HR columns 4x .. 4x+3: one aligned 16-byte read of four
+// backward-map entries, then - when the four entries are consecutive source
+// pixels, the common case for smooth motion - one 16-byte gather per plane;
+// lanes whose entries break fetch the other three pixels one by one.  The 5-tap
+// row pass centred on column 4x is
+//     a0*k0 + (L.a3 + a1)*k1 + (L.a2 + a2)*k2
+// with L the lane to the left (lane 0 only serves as lane 1's left neighbour;
+// at the image's left edge reflect101 maps columns -1, -2 to a1, a2).  The wave
+// walks down its LR rows keeping the five row-pass results of the current LR
+// row in registers (four new HR rows per LR row); the map entries of the next
+// LR row are fetched while the current one is gathered.
+// Signs go to the pair plane (layout at the top of this file).
 // Work items are ordered frame-fastest so that the waves gathering from one
 // region of X run together on one CU / XCD.
-constexpr int kFwdRowsPerWave = 6;
-constexpr int kFwdStrip = 28;
+#ifndef SRX_A_ROWS
+#define SRX_A_ROWS 6
+#endif
+#ifndef SRX_A_WAVES
+#define SRX_A_WAVES 4
+#endif
+constexpr int kFwdRowsPerWave = SRX_A_ROWS;
+constexpr int kFwdStrip = 63;
 
 template <int CH>
-__global__ __launch_bounds__(256) void k_forward_sign_s4(const float* __restrict__ X, int H, int W, PtrList dec_bwd,
-                                                          PtrList ys, MutPtrList signs, int K, GaussK g,
-                                                          int strips_x, unsigned n_items, unsigned n_blocks)
+__global__ __launch_bounds__(256, SRX_A_WAVES) void k_forward_sign_s4(const float* __restrict__ X, int H, int W,
+                                                                       size_t ps, PtrList dec_bwd, PtrList ys,
+                                                                       MutPtrList signs, int K, GaussK g, int strips_x,
+                                                                       unsigned n_items, unsigned n_blocks)
 {
     const unsigned item = xcd_contiguous(blockIdx.x, n_blocks) * 4 + (threadIdx.x >> 6);
     if (item >= n_items)
@@ -539,81 +585,152 @@ __global__ __launch_bounds__(256) void k_forward_sign_s4(const float* __restrict
     const unsigned tile = item / K;
     const int strip = tile % strips_x, rg = tile / strips_x;
     const int h = H >> 2, w = W >> 2;
-    const int lane = threadIdx.x & 63, j = lane >> 4, q = lane & 15;
+    const int lane = threadIdx.x & 63;
     const int x0 = strip * kFwdStrip, y0 = rg * kFwdRowsPerWave;
     const int y1 = min(y0 + kFwdRowsPerWave, h);
 
-    const int col0 = 4 * x0 - 2 + 28 * j + 2 * q; // even register's HR column; the odd register holds col0 + 1
-    const int cA = reflect101(col0, W), cB = reflect101(col0 + 1, W);
-    const bool pair = (cB == cA + 1);             // plain interior lane: one 8-byte map load
-    const int x = x0 + 7 * j + (q >> 1);          // LR pixel centred on col0 (odd lanes 1..13)
-    const bool owner = (q & 1) && q <= 13 && x < w;
+    const int x = x0 - 1 + lane;          // LR column of this lane
+    const int xl = min(max(x, 0), w - 1); // column it loads (clamped copies are never stored)
+    const bool owner = lane >= 1 && x < w;
+    const bool first = x == 0;
 
-    const uint32_t* map = (const uint32_t*)dec_bwd.p[k];
+    const uint32_t* map = (const uint32_t*)dec_bwd.p[k] + 4 * xl;
+    const float* yk = (const float*)ys.p[k] + (size_t)xl * CH;
+    uint32_t* sp = (uint32_t*)signs.p[k] + 2 * (size_t)xl;
     const float k0 = g.k[2], k1 = g.k[3], k2 = g.k[4];
 
-    auto row_pass = [&](int Y, float (&out)[CH]) {
-        const uint32_t* mr = map + (size_t)reflect101(Y, H) * W;
-        uint32_t ia, ib;
-        if (pair)
-        {
-            const uint2 m2 = *(const uint2*)(mr + cA);
-            ia = m2.x, ib = m2.y;
-        }
-        else
-        {
-            ia = mr[cA];
-            ib = mr[cB];
-        }
-        const float* pe = X + (size_t)ia * CH;
-        const float* po = X + (size_t)ib * CH;
+    auto load_map = [&](int Y) { return *(const uint4*)(map + (size_t)reflect101(Y, H) * W); };
+    auto consecutive = [](const uint4& m) { return m.y == m.x + 1 && m.z == m.x + 2 && m.w == m.x + 3; };
+    auto gather = [&](const uint4& m, float4 (&a)[CH]) {
 #pragma unroll
         for (int c = 0; c < CH; ++c)
         {
-            const float e = pe[c], o = po[c];
-            const float u = dpp_from_left(o) + o;                  // columns col0-1, col0+1
-            const float v = dpp_from_left(e) + dpp_from_right(e);  // columns col0-2, col0+2
-            float s = e * k0;
-            s += u * k1;
-            s += v * k2;
+#ifdef SRX_X_ALIGNED
+            const float4_a4 v = *(const float4_a4*)(X + c * ps + (m.x & ~3u));
+#else
+            const float4_a4 v = *(const float4_a4*)(X + c * ps + m.x);
+#endif
+            a[c] = make_float4(v.x, v.y, v.z, v.w);
+        }
+    };
+    auto patch = [&](const uint4& m, float4 (&a)[CH]) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+        {
+            a[c].y = X[c * ps + m.y];
+            a[c].z = X[c * ps + m.z];
+            a[c].w = X[c * ps + m.w];
+        }
+    };
+    auto row_pass = [&](const float4 (&a)[CH], float (&out)[CH]) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+        {
+            float l3 = from_left_lane(a[c].w), l2 = from_left_lane(a[c].z);
+            l3 = first ? a[c].y : l3;
+            l2 = first ? a[c].z : l2;
+            float s = a[c].x * k0;
+            s += (l3 + a[c].y) * k1;
+            s += (l2 + a[c].z) * k2;
             out[c] = s;
         }
     };
 
     float rr[5][CH];
-    row_pass(4 * y0 - 2, rr[0]);
+    uint4 mc[4];
+    {
+        const uint4 m0 = load_map(4 * y0 - 2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            mc[r] = load_map(4 * y0 - 1 + r);
+        float4 a[CH];
+        gather(m0, a);
+        if (!consecutive(m0))
+            patch(m0, a);
+        row_pass(a, rr[0]);
+    }
     for (int y = y0; y < y1; ++y)
     {
+        uint4 mn[4];
 #pragma unroll
-        for (int r = 1; r < 5; ++r)
-            row_pass(4 * y - 2 + r, rr[r]);
+        for (int r = 0; r < 4; ++r)
+            mn[r] = mc[r];
+        if (y + 1 < y1)
+        {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                mn[r] = load_map(4 * y + 3 + r);
+        }
+        float yv[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#ifdef SRX_X_NOY
+            yv[c] = 0.f;
+#else
+            yv[c] = yk[(size_t)y * w * CH + c];
+#endif
+
+        float4 a[4][CH];
+        bool broken = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+        {
+            gather(mc[r], a[r]);
+            broken = broken || !consecutive(mc[r]);
+        }
+#ifndef SRX_X_NOPATCH
+        if (broken)
+        {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (!consecutive(mc[r]))
+                    patch(mc[r], a[r]);
+        }
+#endif
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            row_pass(a[r], rr[r + 1]);
+
+        uint32_t sg = 0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+        {
+            float s = rr[2][c] * k0;
+            s += (rr[1][c] + rr[3][c]) * k1;
+            s += (rr[0][c] + rr[4][c]) * k2;
+            sg |= (uint32_t)((int)dsign(yv[c], s) + 1) << (10 * c);
+        }
         if (owner)
         {
-            const float* yp = (const float*)ys.p[k] + ((size_t)y * w + x) * CH;
-            uint32_t sg = 0;
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-            {
-                float s = rr[2][c] * k0;
-                s += (rr[1][c] + rr[3][c]) * k1;
-                s += (rr[0][c] + rr[4][c]) * k2;
-                sg |= (uint32_t)((int)dsign(yp[c], s) + 1) << (10 * c);
-            }
-            ((uint32_t*)signs.p[k])[(size_t)y * w + x] = sg;
+            sp[2 * (size_t)y * w] = sg;
+            if (y > 0)
+                sp[2 * (size_t)(y - 1) * w + 1] = sg;
         }
 #pragma unroll
         for (int c = 0; c < CH; ++c)
             rr[0][c] = rr[4][c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            mc[r] = mn[r];
     }
 }
 
 // Integer weights of the transposed 5-tap blur for dyadic kernels (k*16 integer):
 // per weight-table index the weights of the 2x2 block of sign cells, in units of
-// 1/256, and their sum (entries 16 and 17 are all zero).
+// 1/256 and in the order of a pair-plane read, and their sum (the last entry is
+// all zero).  `flush` = number of frames whose weighted sign words can be summed in
+// the packed 10-bit fields before they must be unpacked.
 struct FastW
 {
-    uint32_t w[kFwdLutSize][4]; // [AA, AB, BA, BB]
+    uint32_t w[kFwdLutSize][4]; // cells (row, col), (row+1, col), (row, col+1), (row+1, col+1)
     uint32_t wsum[kFwdLutSize];
+    int flush;
+};
+
+// 16 bytes at an 8-byte aligned address: one global_load_dwordx4
+struct __attribute__((packed, aligned(8))) uint4_a8
+{
+    uint32_t x, y, z, w;
 };
 
 // order-preserving float <-> int key (an involution); -0 is folded into +0 so
@@ -638,45 +755,57 @@ __device__ __forceinline__ int key_sign(int a, int b)
 
 // Back-projection of all K frames + BTV regulariser + update for one 64x16 tile
 // of HR pixels per block; each thread owns 4 consecutive pixels of one row.
+// X and X_out are planar.
+//  * BTV: the tile of X (+3 px halo) sits in LDS, one plane per channel, as
+//    order-preserving integer keys; sign(a-b) is a saturating subtract and a
+//    clamp; accumulation order is the reference's (lib/src/btv_l1.cpp:221-233).
+//    Channels are processed one after the other, which keeps the register
+//    windows small.  NaN pixels are ordered as large values instead of
+//    comparing unordered.
 //  * per frame: one 16-byte load of 4 decoded forward-map entries (fetched one
-//    frame ahead), then per pixel the 2x2 block of sign cells times the entry's
-//    integer weights.  Exact for dyadic blur kernels: every partial sum is a
-//    multiple of 1/256.  The loop is branch-free (entries outside the image carry
-//    zero weights) so that all gathers of a frame are in flight together; the
-//    rare targets next to the image edge are added by a second, generic pass.
-//  * BTV: the tile of X (+3 px halo) sits in LDS as order-preserving integer
-//    keys; sign(a-b) is a saturating subtract and a clamp; accumulation order is
-//    the reference's (lib/src/btv_l1.cpp:221-233).  NaN pixels are ordered as
-//    large values instead of comparing unordered.
+//    frame ahead), then per pixel one 16-byte read of the 2x2 block of sign
+//    cells from the pair plane, times the entry's integer weights.  A sign word
+//    times a weight is three products at once (10-bit fields), and the products
+//    of several frames are summed before the fields are unpacked.  Exact for
+//    dyadic blur kernels: every partial sum is a multiple of 1/256.  The loop is
+//    branch-free: entries outside the image carry zero weights, and the
+//    targets next to the image edge have weight-table entries of their own.
+//  * lanes are mapped to tile positions so that each lane group of a
+//    ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) reads 16
+//    consecutive 16-byte chunks of one LDS row: conflict-free at any row pitch.
 #ifndef SRX_B_WAVES
-#define SRX_B_WAVES 4
+#define SRX_B_WAVES 5
 #endif
 template <int CH>
-__global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(const float* __restrict__ X, float* __restrict__ X_out,
-                                                                int H, int W, PtrList dec_fwd, PtrList raw_fwd,
-                                                                PtrList signs, int K, GaussK g, FastW fw, BtvW bw,
-                                                                double tau, double lambda, int tiles_x,
-                                                                unsigned n_tiles)
+__global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
+    const float* __restrict__ X, float* __restrict__ X_out, int H, int W, size_t ps, PtrList dec_fwd,
+    PtrList signs, int K, FastW fw, BtvW bw, double tau, double lambda, int tiles_x, unsigned n_tiles)
 {
-    constexpr int TXN = 16, TYN = 16, PXT = 4;
-    constexpr int TW = TXN * PXT;       // 64 px
+    constexpr int TYN = 16, PXT = 4;
+    constexpr int TW = 16 * PXT;        // 64 px
     constexpr int HALO = 3, HL = 4;     // halo; left halo padded to 4 px so that row loads are 16-byte aligned
-    constexpr int LW = TW + HL + 4;     // 72 px held per LDS row: [j0-4, j0+68)
+    constexpr int PITCH = TW + HL + 4;  // 72 floats per LDS row: columns [j0-4, j0+68)
     constexpr int LROWS = TYN + 2 * HALO;
-    constexpr int PITCH = CH == 3 ? 256 : 128; // floats; a multiple of 64 keeps ds_read_b128 conflict-free
-    constexpr int NV = CH == 3 ? 9 : 3;        // 16-byte LDS reads per window row
-    constexpr int OFF = CH == 3 ? 3 : 1;       // first needed float within the aligned window
-    constexpr int NE = PXT * CH;               // outputs per thread
-    __shared__ __attribute__((aligned(16))) int tile[LROWS * PITCH];
-    __shared__ uint4 lutw[kFwdLutSize];
-    __shared__ uint32_t luts[kFwdLutSize];
+    constexpr int RV = PITCH / 4;       // 16-byte vectors per LDS row
+    constexpr int NV = 3;               // vectors per window row: columns [4tx, 4tx+12) of the LDS row
+    __shared__ __attribute__((aligned(16))) int tile[CH * LROWS * PITCH];
+    __shared__ uint4 lut[2 * kFwdLutSize]; // [li] = weights, [kFwdLutSize + li].x = their sum
+    __shared__ float park[CH * PXT * 256];  // regulariser values rest here while the frame loop runs
 
     const unsigned t = xcd_contiguous(blockIdx.x, n_tiles);
     if (t >= n_tiles)
         return;
     const int j0 = (t % tiles_x) * TW, i0 = (t / tiles_x) * TYN;
     const int tid = threadIdx.x;
-    const int tx = tid & (TXN - 1), ty = tid >> 4;
+    // lane -> (tx, row within the wave's 4 rows), see the note on ds_read_b128 lane groups above
+    int tx, ty;
+    {
+        const int l5 = tid & 31;
+        const int grp = (0x96 >> (l5 >> 2)) & 1; // lanes 0-3,12-15,20-27 -> 0; 4-11,16-19,28-31 -> 1
+        const int pos = l5 < 4 ? l5 : l5 < 12 ? l5 - 4 : l5 < 20 ? l5 - 8 : l5 < 28 ? l5 - 12 : l5 - 16;
+        tx = pos;
+        ty = (tid >> 6) * 4 + ((tid >> 5) & 1) * 2 + grp;
+    }
     const int w = W >> 2;
     const int i = min(i0 + ty, H - 1), j = min(j0 + tx * PXT, W - PXT); // clamped; stores are masked below
     const bool live = (i0 + ty) < H && (j0 + tx * PXT) < W; // W is a multiple of 4: a thread's pixels are all in or all out
@@ -689,100 +818,103 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(cons
 
     if (tid < kFwdLutSize)
     {
-        lutw[tid] = make_uint4(fw.w[tid][0], fw.w[tid][1], fw.w[tid][2], fw.w[tid][3]);
-        luts[tid] = fw.wsum[tid];
+        lut[tid] = make_uint4(fw.w[tid][0], fw.w[tid][1], fw.w[tid][2], fw.w[tid][3]);
+        lut[kFwdLutSize + tid] = make_uint4(fw.wsum[tid], 0, 0, 0);
     }
     // ---- stage the X tile (as keys) in LDS; all loads are issued before the first is consumed
     {
-        constexpr int V4 = LW * CH / 4; // float4 per row: 54 or 18
-        constexpr int NIT = (LROWS * V4 + 255) / 256;
-        const int rowf = W * CH;
+        constexpr int NCH = CH * LROWS * RV; // 16-byte chunks
+        constexpr int NIT = (NCH + 255) / 256;
         float4 stage[NIT];
-        bool have[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
         {
-            const int idx = tid + it * 256;
-            const int r = idx / V4, c4 = idx - r * V4;
-            const int gi = i0 - HALO + r;
-            const int f0 = (j0 - HL) * CH + 4 * c4;
-            have[it] = idx < LROWS * V4 && gi >= 0 && gi < H && f0 >= 0 && f0 + 3 < rowf;
-            stage[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (have[it])
-                stage[it] = *(const float4*)(X + (size_t)gi * rowf + f0);
+            // branch-free: chunks outside the image read a clamped address (and are zeroed below)
+            const int idx = min(tid + it * 256, NCH - 1);
+            const int c = idx / (LROWS * RV), rem = idx - c * (LROWS * RV);
+            const int r = rem / RV, c4 = rem - r * RV;
+            const int gi = min(max(i0 - HALO + r, 0), H - 1), gj = min(max(j0 - HL + 4 * c4, 0), W - 4);
+            stage[it] = *(const float4*)(X + c * ps + (size_t)gi * W + gj);
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
         {
             const int idx = tid + it * 256;
-            const int r = idx / V4, c4 = idx - r * V4;
-            if (idx < LROWS * V4)
+            const int c = idx / (LROWS * RV), rem = idx - c * (LROWS * RV);
+            const int r = rem / RV, c4 = rem - r * RV;
+            const int gi = i0 - HALO + r, gj = j0 - HL + 4 * c4;
+            // W and gj are multiples of 4: a chunk is entirely inside or outside the row
+            const bool in = gi >= 0 && gi < H && gj >= 0 && gj < W;
+            if (idx < NCH)
             {
                 const float4 v = stage[it];
                 // outside the image the tile holds key(0); those cells are never read by an interior pixel
-                *(v4i*)&tile[r * PITCH + 4 * c4] = v4i{float_key(v.x), float_key(v.y), float_key(v.z), float_key(v.w)};
+                *(v4i*)&tile[4 * idx] = in ? v4i{float_key(v.x), float_key(v.y), float_key(v.z), float_key(v.w)}
+                                           : v4i{0, 0, 0, 0};
             }
         }
     }
     __syncthreads();
 
-    // ---- BTV regulariser from the LDS tile
-    float reg[NE];
-#pragma unroll
-    for (int e = 0; e < NE; ++e)
-        reg[e] = 0.0f;
+    // ---- BTV regulariser from the LDS tile, one channel at a time
     const int lrow = ty + HALO;
-    lds_cv4i* tp = (lds_cv4i*)tile + (lrow * PITCH + tx * PXT * CH) / 4; // aligned window start of the centre row
-    constexpr int RV = PITCH / 4;                                        // vectors per LDS row
-    v4i cv[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v)
-        cv[v] = tp[v];
-    const int* cw = (const int*)cv;
-    int ctr[NE];
-#pragma unroll
-    for (int e = 0; e < NE; ++e)
-        ctr[e] = cw[OFF + HALO * CH + e];
     if (lambda > 0)
     {
-        int ind = 0;
 #pragma unroll
-        for (int m = 0; m <= 3; ++m)
+        for (int c = 0; c < CH; ++c)
         {
-            v4i pv[NV], mv[NV];
+            lds_cv4i* tp = (lds_cv4i*)tile + (c * LROWS + lrow) * RV + tx; // window start of the centre row
+            v4i cv[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v)
+                cv[v] = tp[v];
+            const int* cw = (const int*)cv;
+            int ctr[PXT];
+            float reg[PXT];
+#pragma unroll
+            for (int e = 0; e < PXT; ++e)
             {
-                pv[v] = m == 0 ? cv[v] : tp[m * RV + v];
-                mv[v] = m == 0 ? cv[v] : tp[-m * RV + v];
+                ctr[e] = cw[HL + e];
+                reg[e] = 0.0f;
             }
-            const int* pw = (const int*)pv;
-            const int* mw = (const int*)mv;
+
+            int ind = 0;
 #pragma unroll
-            for (int l = 3; l + m >= 0; --l, ++ind)
+            for (int m = 0; m <= 3; ++m)
             {
-                if (m == 0 && l == 0)
-                    continue; // both signs compare the pixel with itself: adds w * 0
-                const float wt = bw.w[ind];
+                v4i pv[NV], mv[NV];
 #pragma unroll
-                for (int e = 0; e < NE; ++e)
+                for (int v = 0; v < NV; ++v)
                 {
-                    const int c0 = OFF + HALO * CH + e;
-                    const int d = key_sign(ctr[e], pw[c0 + CH * l]) + key_sign(ctr[e], mw[c0 - CH * l]);
-                    // w * d is exact (d in -2..2), so the fused form rounds once, like acc += w * d
-                    reg[e] = __builtin_fmaf(wt, (float)d, reg[e]);
+                    pv[v] = m == 0 ? cv[v] : tp[m * RV + v];
+                    mv[v] = m == 0 ? cv[v] : tp[-m * RV + v];
+                }
+                const int* pw = (const int*)pv;
+                const int* mw = (const int*)mv;
+#pragma unroll
+                for (int l = 3; l + m >= 0; --l, ++ind)
+                {
+                    if (m == 0 && l == 0)
+                        continue; // both signs compare the pixel with itself: adds w * 0
+                    const float wt = bw.w[ind];
+#pragma unroll
+                    for (int e = 0; e < PXT; ++e)
+                    {
+                        const int d = key_sign(ctr[e], pw[HL + e + l]) + key_sign(ctr[e], mw[HL + e - l]);
+                        // w * d is exact (d in -2..2), so the fused form rounds once, like acc += w * d
+                        reg[e] = __builtin_fmaf(wt, (float)d, reg[e]);
+                    }
                 }
             }
-            // keep the next row pair's LDS reads behind this pair's arithmetic: hoisting them
-            // would hold several 36-register windows live at once
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < PXT; ++e)
+                park[(c * PXT + e) * 256 + tid] = reg[e];
         }
     }
 
     // ---- sum over frames of M^T H^T D^T sign, in units of 1/256
     int acc[PXT][CH];
     int bias[PXT];
-    uint32_t slow = 0;
 #pragma unroll
     for (int p = 0; p < PXT; ++p)
     {
@@ -791,112 +923,151 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(cons
         for (int c = 0; c < CH; ++c)
             acc[p][c] = 0;
     }
-#ifndef SRX_B_UNROLL
-#define SRX_B_UNROLL 1
-#endif
-    // the next frame's map entries are fetched while the current frame's sign cells are gathered
-#pragma unroll SRX_B_UNROLL
-    for (int k = 0; k < K; ++k)
+    const char* lutb = (const char*)lut;
     {
-        uint4 nxt = cur;
-        if (k + 1 < K)
-            nxt = *(const uint4*)((const uint32_t*)dec_fwd.p[k + 1] + pix);
-        const uint32_t* sg = (const uint32_t*)signs.p[k];
-        const uint32_t ev[PXT] = {cur.x, cur.y, cur.z, cur.w};
+        // Two frames deep: while frame k's sign cells are consumed, frame k+1's are in flight and
+        // frame k+2's map entries are being fetched.
+        uint32_t accv[PXT];
 #pragma unroll
         for (int p = 0; p < PXT; ++p)
-        {
-            const uint32_t e = ev[p];
-            const uint32_t* s0 = sg + (e & kFwdCellMask);
-            const uint32_t li = e >> kFwdLutShift;
-            const uint4 wq = lutw[li];
-            // operands fit 24 bits: full-rate v_mad_u32_u24
-            uint32_t v = __umul24(s0[0], wq.x);
-            v += __umul24(s0[1], wq.y);
-            v += __umul24(s0[w], wq.z);
-            v += __umul24(s0[w + 1], wq.w);
-            bias[p] += luts[li];
-            slow |= (li == kFwdLutSlow) ? 1u : 0u;
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-                acc[p][c] += (int)((v >> (10 * c)) & 1023u);
-        }
-        cur = nxt;
-    }
-    if (slow)
-    {
-        // targets within 2 px of the image edge: generic evaluation with reflect101
+            accv[p] = 0;
+        auto gather = [&](int k, const uint4& m, uint4_a8 (&q)[PXT]) {
+            const char* sg = (const char*)signs.p[k];
+            q[0] = *(const uint4_a8*)(sg + (m.x & kFwdCellMask));
+            q[1] = *(const uint4_a8*)(sg + (m.y & kFwdCellMask));
+            q[2] = *(const uint4_a8*)(sg + (m.z & kFwdCellMask));
+            q[3] = *(const uint4_a8*)(sg + (m.w & kFwdCellMask));
+        };
+        uint4 m1 = cur;
+        if (K > 1)
+            m1 = *(const uint4*)((const uint32_t*)dec_fwd.p[1] + pix);
+        uint4_a8 q0[PXT];
+        if (K > 0)
+            gather(0, cur, q0);
+        int pending = 0;
         for (int k = 0; k < K; ++k)
         {
-            const uint32_t* sg = (const uint32_t*)signs.p[k];
-            const uint32_t* de = (const uint32_t*)dec_fwd.p[k] + pix;
-#pragma unroll 1
-            for (int pp = 0; pp < PXT; ++pp)
+            uint4 m2 = m1;
+            if (k + 2 < K)
+                m2 = *(const uint4*)((const uint32_t*)dec_fwd.p[k + 2] + pix);
+            uint4_a8 q1[PXT];
+#pragma unroll
+            for (int p = 0; p < PXT; ++p)
+                q1[p] = q0[p];
+            if (k + 1 < K)
+                gather(k + 1, m1, q1);
+            __builtin_amdgcn_sched_barrier(0); // the next frame's gathers are issued before this frame's are consumed
+            const uint32_t ev[PXT] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+            for (int p = 0; p < PXT; ++p)
             {
-                if ((de[pp] >> kFwdLutShift) != kFwdLutSlow)
-                    continue;
-                const short2 m = ((const short2*)raw_fwd.p[k])[pix + pp];
-                float a[CH];
-                backproject_generic<CH>(sg, H, W, 4, m.x, m.y, g, a);
+                const uint32_t e = ev[p];
+                const uint4_a8 q = q0[p];
+                const char* le = lutb + ((e >> (kFwdLutShift - 4)) & 0x1F0u);
+                const uint4 wq = *(const uint4*)le;
+                // operands fit 24 bits: full-rate v_mad_u32_u24
+                uint32_t v = accv[p];
+                v += __umul24(q.x, wq.x);
+                v += __umul24(q.y, wq.y);
+                v += __umul24(q.z, wq.z);
+                v += __umul24(q.w, wq.w);
+                accv[p] = v;
+                bias[p] += *(const uint32_t*)(le + kFwdLutSize * 16);
+            }
+            if (++pending == fw.flush || k + 1 == K)
+            {
+                // unpack the 10-bit fields before they can overflow
 #pragma unroll
                 for (int p = 0; p < PXT; ++p)
+                {
 #pragma unroll
                     for (int c = 0; c < CH; ++c)
-                        acc[p][c] += p == pp ? (int)(a[c] * 256.0f) : 0;
+                        acc[p][c] += (int)((accv[p] >> (10 * c)) & 1023u);
+                    accv[p] = 0;
+                }
+                pending = 0;
             }
+            cur = m1;
+            m1 = m2;
+#pragma unroll
+            for (int p = 0; p < PXT; ++p)
+                q0[p] = q1[p];
         }
     }
-
     // ---- update
     if (!live)
         return;
-    float outv[NE];
 #pragma unroll
-    for (int p = 0; p < PXT; ++p)
+    for (int c = 0; c < CH; ++c)
     {
-        const bool interior = i >= HALO && i < H - HALO && (j + p) >= HALO && (j + p) < W - HALO;
+        // the centre pixels come back from the tile, the regulariser from its parking slot
+        const v4i ctr = ((lds_cv4i*)tile)[(c * LROWS + lrow) * RV + tx + HL / 4];
+        float outv[PXT];
 #pragma unroll
-        for (int c = 0; c < CH; ++c)
+        for (int p = 0; p < PXT; ++p)
         {
-            const int e = p * CH + c;
+            const bool interior = i >= HALO && i < H - HALO && (j + p) >= HALO && (j + p) < W - HALO;
             float d = (float)(acc[p][c] - bias[p]) * 0.00390625f;
             if (lambda > 0)
             {
-                const float rg = interior ? reg[e] : 0.0f;
+                const float rg = interior ? park[(c * PXT + p) * 256 + tid] : 0.0f;
                 d = (float)((double)d + (double)rg * (-lambda));
             }
-            outv[e] = (float)((double)key_float(ctr[e]) + (double)d * tau);
+            outv[p] = (float)((double)key_float(ctr[p]) + (double)d * tau);
         }
+        *(float4*)(X_out + c * ps + pix) = make_float4(outv[0], outv[1], outv[2], outv[3]);
     }
-    float4* D = (float4*)(X_out + pix * CH);
-#pragma unroll
-    for (int v = 0; v < NE / 4; ++v)
-        D[v] = make_float4(outv[4 * v], outv[4 * v + 1], outv[4 * v + 2], outv[4 * v + 3]);
+}
+
+// plain sign plane <-> pair plane (stage-level entry points)
+__global__ void k_sign_pairs(const uint32_t* __restrict__ plain, uint2* __restrict__ pairs, int h, int w)
+{
+    const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)h * w;
+    if (o > n)
+        return;
+    uint2 v = make_uint2(0, 0); // the spare cell and the row below the last are zero
+    if (o < n)
+    {
+        v.x = plain[o];
+        if (o + w < n)
+            v.y = plain[o + w];
+    }
+    pairs[o] = v;
+}
+__global__ void k_sign_unpair(const uint2* __restrict__ pairs, uint32_t* __restrict__ plain, size_t n)
+{
+    const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o < n)
+        plain[o] = pairs[o].x;
 }
 
 // ---------------------------------------------------------------------------
+// ps == 0: interleaved source; otherwise planar with plane stride ps
 template <int CH, bool TO8U>
-__global__ void k_crop_convert(const float* __restrict__ X, int rows, int cols, int border, void* __restrict__ dst)
+__global__ void k_crop_convert(const float* __restrict__ X, int rows, int cols, int border, void* __restrict__ dst,
+                               size_t ps)
 {
     const int oc = cols - 2 * border, orr = rows - 2 * border;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= oc || y >= orr)
         return;
-    const float* P = X + ((size_t)(y + border) * cols + (x + border)) * CH;
+    const size_t pi = (size_t)(y + border) * cols + (x + border);
     const size_t o = ((size_t)y * oc + x) * CH;
 #pragma unroll
     for (int c = 0; c < CH; ++c)
     {
+        const float v = X[ps ? c * ps + pi : pi * CH + c];
         if (TO8U)
         {
             // convertTo(CV_8U): cvRound (half to even) then clamp; NaN -> 0
-            float r = rintf(P[c]);
+            float r = rintf(v);
             r = fminf(fmaxf(r, 0.0f), 255.0f);
             ((uint8_t*)dst)[o + c] = (uint8_t)(int)r;
         }
         else
-            ((float*)dst)[o + c] = P[c];
+            ((float*)dst)[o + c] = v;
     }
 }
 
@@ -962,19 +1133,36 @@ int launch_decode_maps(const int16_t* fwd_map, const int16_t* bwd_map, int hr_ro
 }
 
 int launch_resize_cubic(const float* src, int srows, int scols, int ch, const CubicTables& t, float* dst, int drows,
-                        int dcols, hipStream_t st)
+                        int dcols, size_t plane_stride, hipStream_t st)
 {
     const dim3 b(64, 4);
     const dim3 g = grid2d(dcols, drows, b);
     switch (ch)
     {
-    case 1: hipLaunchKernelGGL(k_resize_cubic<1>, g, b, 0, st, src, srows, scols, t, dst, drows, dcols); break;
-    case 2: hipLaunchKernelGGL(k_resize_cubic<2>, g, b, 0, st, src, srows, scols, t, dst, drows, dcols); break;
-    case 3: hipLaunchKernelGGL(k_resize_cubic<3>, g, b, 0, st, src, srows, scols, t, dst, drows, dcols); break;
-    case 4: hipLaunchKernelGGL(k_resize_cubic<4>, g, b, 0, st, src, srows, scols, t, dst, drows, dcols); break;
+    case 1: hipLaunchKernelGGL(k_resize_cubic<1>, g, b, 0, st, src, srows, scols, t, dst, drows, dcols, plane_stride); break;
+    case 2: hipLaunchKernelGGL(k_resize_cubic<2>, g, b, 0, st, src, srows, scols, t, dst, drows, dcols, plane_stride); break;
+    case 3: hipLaunchKernelGGL(k_resize_cubic<3>, g, b, 0, st, src, srows, scols, t, dst, drows, dcols, plane_stride); break;
+    case 4: hipLaunchKernelGGL(k_resize_cubic<4>, g, b, 0, st, src, srows, scols, t, dst, drows, dcols, plane_stride); break;
     default: set_error("resize_cubic: channels must be 1..4"); return 1;
     }
     return check_launch("resize_cubic");
+}
+
+int launch_relayout(const float* src, float* dst, size_t pixels, int ch, size_t plane_stride, bool to_planar,
+                    hipStream_t st)
+{
+    const int bs = 256;
+    const dim3 g((unsigned)((pixels + bs - 1) / bs));
+    if (ch == 1)
+        hipLaunchKernelGGL(k_relayout<1>, g, dim3(bs), 0, st, src, dst, pixels, plane_stride, to_planar ? 1 : 0);
+    else if (ch == 3)
+        hipLaunchKernelGGL(k_relayout<3>, g, dim3(bs), 0, st, src, dst, pixels, plane_stride, to_planar ? 1 : 0);
+    else
+    {
+        set_error("relayout: channels must be 1 or 3");
+        return 1;
+    }
+    return check_launch("relayout");
 }
 
 int launch_btv_regularization(const float* src, int rows, int cols, int ch, const BtvW& w, float* dst, hipStream_t st)
@@ -988,6 +1176,24 @@ int launch_btv_regularization(const float* src, int rows, int cols, int ch, cons
     default: set_error("btv_regularization: channels must be 1 or 3"); return 1;
     }
     return check_launch("btv_regularization");
+}
+
+int launch_sign_pairs(const uint32_t* plain, uint32_t* pairs, int lr_rows, int lr_cols, hipStream_t st)
+{
+    const int bs = 256;
+    const size_t n = (size_t)lr_rows * lr_cols + 1;
+    hipLaunchKernelGGL(k_sign_pairs, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, plain, (uint2*)pairs,
+                       lr_rows, lr_cols);
+    return check_launch("sign_pairs");
+}
+
+int launch_sign_unpair(const uint32_t* pairs, uint32_t* plain, int lr_rows, int lr_cols, hipStream_t st)
+{
+    const int bs = 256;
+    const size_t n = (size_t)lr_rows * lr_cols;
+    hipLaunchKernelGGL(k_sign_unpair, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, (const uint2*)pairs, plain,
+                       n);
+    return check_launch("sign_unpair");
 }
 
 bool forward_fast_eligible(int hr_rows, int hr_cols, int ch, int scale, const GaussK& g)
@@ -1008,16 +1214,17 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
     if (dec_bwd && forward_fast_eligible(hr_rows, hr_cols, ch, scale, g))
     {
         const int w = hr_cols / 4, h = hr_rows / 4;
+        const size_t ps = plane_stride_for((size_t)hr_rows * hr_cols);
         const int strips_x = (w + kFwdStrip - 1) / kFwdStrip;
         const int row_groups = (h + kFwdRowsPerWave - 1) / kFwdRowsPerWave;
         const unsigned n_items = (unsigned)strips_x * row_groups * K; // one wave each
         const unsigned n_blocks = (n_items + 3) / 4;
         const dim3 gr(xcd_grid(n_blocks)), b(256);
         if (ch == 1)
-            hipLaunchKernelGGL(k_forward_sign_s4<1>, gr, b, 0, st, X, hr_rows, hr_cols, *dec_bwd, y, signs, K, g,
+            hipLaunchKernelGGL(k_forward_sign_s4<1>, gr, b, 0, st, X, hr_rows, hr_cols, ps, *dec_bwd, y, signs, K, g,
                                strips_x, n_items, n_blocks);
         else
-            hipLaunchKernelGGL(k_forward_sign_s4<3>, gr, b, 0, st, X, hr_rows, hr_cols, *dec_bwd, y, signs, K, g,
+            hipLaunchKernelGGL(k_forward_sign_s4<3>, gr, b, 0, st, X, hr_rows, hr_cols, ps, *dec_bwd, y, signs, K, g,
                                strips_x, n_items, n_blocks);
         return check_launch("forward_sign_s4");
     }
@@ -1044,22 +1251,25 @@ static bool make_fast_weights(const GaussK& g, FastW& fw)
             return false;
         ki[i] = (int)v;
     }
-    // per phase p = f & 3: slot A carries tap j = {0,-1,-2,+1}[p], slot B only exists for p == 2 (tap +2)
-    const int gA[4] = {ki[0], ki[1], ki[2], ki[1]};
-    const int gB[4] = {0, 0, ki[2], 0};
+    // per phase p: slot A carries tap j = {0,-1,-2,+1,-2}[p], slot B only exists for p == 2 (tap +2)
+    const int gA[5] = {ki[0], ki[1], ki[2], ki[1], ki[2]};
+    const int gB[5] = {0, 0, ki[2], 0, 0};
     std::memset(&fw, 0, sizeof(fw));
-    for (int py = 0; py < 4; ++py)
-        for (int px = 0; px < 4; ++px)
+    uint32_t wmax = 0;
+    for (int py = 0; py < 5; ++py)
+        for (int px = 0; px < 5; ++px)
         {
-            const int p = px | (py << 2);
-            fw.w[p][0] = gA[px] * gA[py];
-            fw.w[p][1] = gB[px] * gA[py];
-            fw.w[p][2] = gA[px] * gB[py];
-            fw.w[p][3] = gB[px] * gB[py];
+            const int p = px + 5 * py;
+            fw.w[p][0] = gA[px] * gA[py]; // (row, col)
+            fw.w[p][1] = gA[px] * gB[py]; // (row+1, col)
+            fw.w[p][2] = gB[px] * gA[py]; // (row, col+1)
+            fw.w[p][3] = gB[px] * gB[py]; // (row+1, col+1)
             fw.wsum[p] = fw.w[p][0] + fw.w[p][1] + fw.w[p][2] + fw.w[p][3];
-            if (2 * fw.wsum[p] > 1023u)
-                return false; // 10-bit fields
+            wmax = fw.wsum[p] > wmax ? fw.wsum[p] : wmax;
         }
+    if (wmax == 0 || 2 * wmax > 1023u)
+        return false; // 10-bit fields
+    fw.flush = (int)(1023u / (2 * wmax));
     return true;
 }
 
@@ -1067,7 +1277,7 @@ bool backproject_fast_eligible(int hr_rows, int hr_cols, int ch, int scale, cons
 {
     FastW fw;
     return scale == 4 && w.radius == 3 && (ch == 1 || ch == 3) && hr_rows % 4 == 0 && hr_cols % 4 == 0 &&
-           (size_t)(hr_rows / 4) * (hr_cols / 4) < (1u << 24) && make_fast_weights(g, fw);
+           ((size_t)(hr_rows / 4) * (hr_cols / 4) + 1) * 8 <= (1u << 24) && make_fast_weights(g, fw);
 }
 
 int launch_backproject_update(const float* X, float* X_out, int hr_rows, int hr_cols, int ch, const PtrList& raw_fwd,
@@ -1083,14 +1293,15 @@ int launch_backproject_update(const float* X, float* X_out, int hr_rows, int hr_
     if (dec_fwd && backproject_fast_eligible(hr_rows, hr_cols, ch, scale, g, w) && make_fast_weights(g, fw))
     {
         const int tiles_x = (hr_cols + 63) / 64, tiles_y = (hr_rows + 15) / 16;
+        const size_t ps = plane_stride_for((size_t)hr_rows * hr_cols);
         const unsigned n_tiles = (unsigned)tiles_x * tiles_y;
         const dim3 gr(xcd_grid(n_tiles)), b(256);
         if (ch == 1)
-            hipLaunchKernelGGL(k_backproject_update_s4<1>, gr, b, 0, st, X, X_out, hr_rows, hr_cols, *dec_fwd, raw_fwd,
-                               signs, K, g, fw, w, tau, lambda, tiles_x, n_tiles);
+            hipLaunchKernelGGL(k_backproject_update_s4<1>, gr, b, 0, st, X, X_out, hr_rows, hr_cols, ps, *dec_fwd,
+                               signs, K, fw, w, tau, lambda, tiles_x, n_tiles);
         else
-            hipLaunchKernelGGL(k_backproject_update_s4<3>, gr, b, 0, st, X, X_out, hr_rows, hr_cols, *dec_fwd, raw_fwd,
-                               signs, K, g, fw, w, tau, lambda, tiles_x, n_tiles);
+            hipLaunchKernelGGL(k_backproject_update_s4<3>, gr, b, 0, st, X, X_out, hr_rows, hr_cols, ps, *dec_fwd,
+                               signs, K, fw, w, tau, lambda, tiles_x, n_tiles);
         return check_launch("backproject_update_s4");
     }
     const dim3 b(64, 4);
@@ -1104,19 +1315,20 @@ int launch_backproject_update(const float* X, float* X_out, int hr_rows, int hr_
     return check_launch("backproject_update");
 }
 
-int launch_crop_convert(const float* X, int rows, int cols, int ch, int border, void* dst, int depth, hipStream_t st)
+int launch_crop_convert(const float* X, int rows, int cols, int ch, int border, void* dst, int depth,
+                        size_t plane_stride, hipStream_t st)
 {
     const dim3 b(64, 4);
     const dim3 g = grid2d(cols - 2 * border, rows - 2 * border, b);
     const bool u8 = depth == 0;
     if (ch == 1 && u8)
-        hipLaunchKernelGGL((k_crop_convert<1, true>), g, b, 0, st, X, rows, cols, border, dst);
+        hipLaunchKernelGGL((k_crop_convert<1, true>), g, b, 0, st, X, rows, cols, border, dst, plane_stride);
     else if (ch == 1)
-        hipLaunchKernelGGL((k_crop_convert<1, false>), g, b, 0, st, X, rows, cols, border, dst);
+        hipLaunchKernelGGL((k_crop_convert<1, false>), g, b, 0, st, X, rows, cols, border, dst, plane_stride);
     else if (ch == 3 && u8)
-        hipLaunchKernelGGL((k_crop_convert<3, true>), g, b, 0, st, X, rows, cols, border, dst);
+        hipLaunchKernelGGL((k_crop_convert<3, true>), g, b, 0, st, X, rows, cols, border, dst, plane_stride);
     else if (ch == 3)
-        hipLaunchKernelGGL((k_crop_convert<3, false>), g, b, 0, st, X, rows, cols, border, dst);
+        hipLaunchKernelGGL((k_crop_convert<3, false>), g, b, 0, st, X, rows, cols, border, dst, plane_stride);
     else
     {
         set_error("crop_convert: channels must be 1 or 3");

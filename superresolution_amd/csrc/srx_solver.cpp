@@ -213,10 +213,10 @@ CubicTables CubicTablesDev::view() const
 int Solver::ensure(int K, int rows, int cols, int ch, int scale, hipStream_t st)
 {
     const size_t hr_px = (size_t)rows * scale * cols * scale;
-    // HR images carry one extra zero pixel; sign planes one extra row and word
-    // (the specialised kernels read, with weight 0, one cell past the last)
-    const size_t x_bytes = (hr_px + 1) * ch * sizeof(float);
-    const size_t sign_bytes = ((size_t)(rows + 1) * cols + 1) * sizeof(uint32_t);
+    // HR images carry one extra zero pixel; sign buffers are sized for the pair plane of the
+    // specialised kernels (the generic ones use the first rows*cols words)
+    const size_t x_bytes = plane_stride_for(hr_px) * ch * sizeof(float);
+    const size_t sign_bytes = sign_pair_bytes(rows, cols);
     const size_t rel_bytes = (size_t)rows * cols * 2 * sizeof(float);
     const bool dec = scale == 4 && g_kernel_path == 0;
     if ((int)fwd_maps_.size() < K)
@@ -260,7 +260,9 @@ int Solver::ensure(int K, int rows, int cols, int ch, int scale, hipStream_t st)
     {
         if (int rc = x_[i].reserve(x_bytes))
             return rc;
-        SRX_HIP(hipMemsetAsync(x_[i].as<float>() + hr_px * ch, 0, ch * sizeof(float), st));
+        // the zero pixel at index hr_px of every plane (planar layout of the specialised kernels)
+        for (int c = 0; c < ch; ++c)
+            SRX_HIP(hipMemsetAsync(x_[i].as<float>() + c * plane_stride_for(hr_px) + hr_px, 0, 4 * sizeof(float), st));
     }
     return tables_.ensure(rows, cols, rows * scale, cols * scale, st);
 }
@@ -349,9 +351,11 @@ int Solver::run(const float* const* y, const float* const* rel, int K, int base_
     }
 
     const CubicTables t = tables_.view();
-    const bool auto_path = g_kernel_path == 0;
-    const bool fastA = auto_path && forward_fast_eligible((int)R, (int)C, ch, s, gauss_);
-    const bool fastB = auto_path && backproject_fast_eligible((int)R, (int)C, ch, s, gauss_, btv_);
+    // the specialised kernels keep X planar, so they are used together or not at all
+    const bool fast = g_kernel_path == 0 && forward_fast_eligible((int)R, (int)C, ch, s, gauss_) &&
+                      backproject_fast_eligible((int)R, (int)C, ch, s, gauss_, btv_);
+    const bool fastA = fast, fastB = fast;
+    ps_ = fast ? plane_stride_for((size_t)R * C) : 0;
     PtrList fwd{}, bwd{}, dfwd{}, dbwd{}, ys{}, sg{};
     MutPtrList sgm{};
     for (int k = 0; k < K; ++k)
@@ -371,7 +375,7 @@ int Solver::run(const float* const* y, const float* const* rel, int K, int base_
 
     // initial estimation (lib/src/btv_l1.cpp:412)
     cur_ = 0;
-    if (int rc = launch_resize_cubic(y[base_idx], rows, cols, ch, t, x_[0].as<float>(), (int)R, (int)C, st))
+    if (int rc = launch_resize_cubic(y[base_idx], rows, cols, ch, t, x_[0].as<float>(), (int)R, (int)C, ps_, st))
         return rc;
 
     if (timing_)
@@ -406,11 +410,19 @@ int Solver::run(const float* const* y, const float* const* rel, int K, int base_
         pending_iters_ = p.iterations;
 
     if (out)
-        if (int rc = launch_crop_convert(x_[cur_].as<float>(), (int)R, (int)C, ch, B, out, SRX_32F, st))
+        if (int rc = launch_crop_convert(x_[cur_].as<float>(), (int)R, (int)C, ch, B, out, SRX_32F, ps_, st))
             return rc;
     if (x_full)
-        SRX_HIP(hipMemcpyAsync(x_full, x_[cur_].get(), (size_t)R * C * ch * sizeof(float), hipMemcpyDeviceToDevice,
-                               st));
+    {
+        if (ps_)
+        {
+            if (int rc = launch_relayout(x_[cur_].as<float>(), x_full, (size_t)R * C, ch, ps_, false, st))
+                return rc;
+        }
+        else
+            SRX_HIP(hipMemcpyAsync(x_full, x_[cur_].get(), (size_t)R * C * ch * sizeof(float),
+                                   hipMemcpyDeviceToDevice, st));
+    }
     return SRX_OK;
 }
 
