@@ -1117,7 +1117,7 @@ SRX_API int srx_k_forward_sign(const float* X, int hr_rows, int hr_cols, int ch,
         DeviceBuffer xpl, dec, pairs;
         if (int rc = xpl.reserve(ps * ch * sizeof(float)))
             return rc;
-        if (int rc = dec.reserve(px * 4))
+        if (int rc = dec.reserve(dec_bwd_words(px) * 4))
             return rc;
         if (int rc = pairs.reserve(sign_pair_bytes(hr_rows / 4, hr_cols / 4)))
             return rc;

@@ -58,7 +58,12 @@ int hip_fail(hipError_t e, const char* what);
 // ---- launchers (srx_kernels.hip) -----------------------------------------
 int launch_relative_motions(const PtrList& fwd, const MutPtrList& rel, int n, int base_idx, size_t count,
                             hipStream_t st);
-// dec_fwd / dec_bwd (optional, scale 4 only): decoded maps for the specialised kernels
+// dec_fwd / dec_bwd (optional, scale 4 only): decoded maps for the specialised kernels;
+// dec_bwd holds dec_bwd_words(hr pixels) words (the map and its group map)
+inline size_t dec_bwd_words(size_t hr_px)
+{
+    return hr_px + hr_px / 4;
+}
 int launch_build_maps(const float* rel, int rows, int cols, int scale, const CubicTables& t, int16_t* fwd_map,
                       int16_t* bwd_map, uint32_t* dec_fwd, uint32_t* dec_bwd, hipStream_t st);
 int launch_decode_maps(const int16_t* fwd_map, const int16_t* bwd_map, int hr_rows, int hr_cols, uint32_t* dec_fwd,

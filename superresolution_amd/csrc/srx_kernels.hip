@@ -17,7 +17,11 @@
 //   decoded maps  one uint32 per HR pixel, derived from the raw maps for the
 //                 specialised kernels:
 //                   backward: linear source pixel index, or rows*cols (the
-//                             zero pixel) when the source is outside;
+//                             zero pixel) when the source is outside; behind
+//                             the rows*cols entries follows the group map, one
+//                             word per 4 pixels of a row: the first entry of
+//                             the group, with bit 31 set when the four entries
+//                             are consecutive source pixels;
 //                   forward:  see kFwd* below.
 //   signs         one uint32 word per LR pixel and window frame: sign+1 (0,1,2)
 //                 of channel c in bits 10c..10c+1.  Generic kernels keep a
@@ -204,6 +208,17 @@ __global__ void k_decode_maps(const short2* __restrict__ fwd_map, const short2* 
         dec_bwd[o] = decode_bwd(bwd_map[o].x, bwd_map[o].y, R, C);
     if (dec_fwd)
         dec_fwd[o] = decode_fwd(fwd_map[o].x, fwd_map[o].y, R, C);
+}
+
+// group map behind the decoded backward map (layout at the top of this file)
+__global__ void k_group_maps(uint32_t* __restrict__ dec_bwd, size_t groups)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups)
+        return;
+    const uint4 m = ((const uint4*)dec_bwd)[g];
+    const bool cons = m.y == m.x + 1 && m.z == m.x + 2 && m.w == m.x + 3;
+    dec_bwd[4 * groups + g] = m.x | (cons ? 0x80000000u : 0u);
 }
 
 // ps == 0: interleaved destination; otherwise planar with plane stride ps
@@ -544,6 +559,11 @@ struct __attribute__((packed, aligned(4))) float4_a4
 {
     float x, y, z, w;
 };
+// N floats fetched by one load instruction
+template <int N> struct __attribute__((packed, aligned(4))) packed_floats
+{
+    float v[N];
+};
 
 // Forward chain sign(y_k - D H M_k X), one wave per (strip of 63 LR columns,
 // group of LR rows, window frame).  X is planar.
@@ -594,32 +614,48 @@ __global__ __launch_bounds__(256, SRX_A_WAVES) void k_forward_sign_s4(const floa
     const bool owner = lane >= 1 && x < w;
     const bool first = x == 0;
 
-    const uint32_t* map = (const uint32_t*)dec_bwd.p[k] + 4 * xl;
+    const uint32_t* map = (const uint32_t*)dec_bwd.p[k] + 4 * xl;      // full entries (lanes with a break only)
+    const uint32_t* grp = (const uint32_t*)dec_bwd.p[k] + (size_t)H * W + xl; // group map
     const float* yk = (const float*)ys.p[k] + (size_t)xl * CH;
     uint32_t* sp = (uint32_t*)signs.p[k] + 2 * (size_t)xl;
     const float k0 = g.k[2], k1 = g.k[3], k2 = g.k[4];
 
-    auto load_map = [&](int Y) { return *(const uint4*)(map + (size_t)reflect101(Y, H) * W); };
-    auto consecutive = [](const uint4& m) { return m.y == m.x + 1 && m.z == m.x + 2 && m.w == m.x + 3; };
-    auto gather = [&](const uint4& m, float4 (&a)[CH]) {
+    auto load_group = [&](int Y) { return grp[(size_t)reflect101(Y, H) * w]; };
+    auto consecutive = [](uint32_t gm) { return (gm >> 31) != 0; };
+    auto gather = [&](uint32_t gm, float4 (&a)[CH]) {
 #pragma unroll
         for (int c = 0; c < CH; ++c)
         {
-#ifdef SRX_X_ALIGNED
-            const float4_a4 v = *(const float4_a4*)(X + c * ps + (m.x & ~3u));
-#else
-            const float4_a4 v = *(const float4_a4*)(X + c * ps + m.x);
-#endif
+            const float4_a4 v = *(const float4_a4*)(X + c * ps + (gm & 0x7fffffffu));
             a[c] = make_float4(v.x, v.y, v.z, v.w);
         }
     };
-    auto patch = [&](const uint4& m, float4 (&a)[CH]) {
+    // Entries that are not one run of consecutive pixels are usually two runs (one break): the
+    // pixels that do not continue the run from m.x are taken from a second gather that ends at
+    // m.w; what neither run covers is fetched pixel by pixel.
+    auto patch = [&](int Y, float4 (&a)[CH]) {
+        const uint4 m = *(const uint4*)(map + (size_t)reflect101(Y, H) * W);
+        const bool rok = m.w >= 3u;
+        const uint32_t rb = rok ? m.w - 3u : 0u;
+        const bool l1 = m.y == m.x + 1, l2 = m.z == m.x + 2, l3 = m.w == m.x + 3;
+        const bool r1 = rok && m.y == rb + 1, r2 = rok && m.z == rb + 2;
 #pragma unroll
         for (int c = 0; c < CH; ++c)
         {
-            a[c].y = X[c * ps + m.y];
-            a[c].z = X[c * ps + m.z];
-            a[c].w = X[c * ps + m.w];
+            const packed_floats<3> v = *(const packed_floats<3>*)(X + c * ps + rb + 1);
+            a[c].y = l1 ? a[c].y : v.v[0];
+            a[c].z = l2 ? a[c].z : v.v[1];
+            a[c].w = l3 ? a[c].w : v.v[2];
+        }
+        if (!((l1 || r1) && (l2 || r2) && (l3 || rok)))
+        {
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+            {
+                a[c].y = X[c * ps + m.y];
+                a[c].z = X[c * ps + m.z];
+                a[c].w = X[c * ps + m.w];
+            }
         }
     };
     auto row_pass = [&](const float4 (&a)[CH], float (&out)[CH]) {
@@ -637,21 +673,21 @@ __global__ __launch_bounds__(256, SRX_A_WAVES) void k_forward_sign_s4(const floa
     };
 
     float rr[5][CH];
-    uint4 mc[4];
+    uint32_t mc[4];
     {
-        const uint4 m0 = load_map(4 * y0 - 2);
+        const uint32_t m0 = load_group(4 * y0 - 2);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            mc[r] = load_map(4 * y0 - 1 + r);
+            mc[r] = load_group(4 * y0 - 1 + r);
         float4 a[CH];
         gather(m0, a);
         if (!consecutive(m0))
-            patch(m0, a);
+            patch(4 * y0 - 2, a);
         row_pass(a, rr[0]);
     }
     for (int y = y0; y < y1; ++y)
     {
-        uint4 mn[4];
+        uint32_t mn[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             mn[r] = mc[r];
@@ -659,16 +695,15 @@ __global__ __launch_bounds__(256, SRX_A_WAVES) void k_forward_sign_s4(const floa
         {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                mn[r] = load_map(4 * y + 3 + r);
+                mn[r] = load_group(4 * y + 3 + r);
         }
         float yv[CH];
+        {
+            const packed_floats<CH> v = *(const packed_floats<CH>*)(yk + (size_t)y * w * CH);
 #pragma unroll
-        for (int c = 0; c < CH; ++c)
-#ifdef SRX_X_NOY
-            yv[c] = 0.f;
-#else
-            yv[c] = yk[(size_t)y * w * CH + c];
-#endif
+            for (int c = 0; c < CH; ++c)
+                yv[c] = v.v[c];
+        }
 
         float4 a[4][CH];
         bool broken = false;
@@ -678,15 +713,13 @@ __global__ __launch_bounds__(256, SRX_A_WAVES) void k_forward_sign_s4(const floa
             gather(mc[r], a[r]);
             broken = broken || !consecutive(mc[r]);
         }
-#ifndef SRX_X_NOPATCH
         if (broken)
         {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (!consecutive(mc[r]))
-                    patch(mc[r], a[r]);
+                    patch(4 * y - 1 + r, a[r]);
         }
-#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             row_pass(a[r], rr[r + 1]);
@@ -925,47 +958,30 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
     }
     const char* lutb = (const char*)lut;
     {
-        // Two frames deep: while frame k's sign cells are consumed, frame k+1's are in flight and
-        // frame k+2's map entries are being fetched.
         uint32_t accv[PXT];
 #pragma unroll
         for (int p = 0; p < PXT; ++p)
             accv[p] = 0;
-        auto gather = [&](int k, const uint4& m, uint4_a8 (&q)[PXT]) {
-            const char* sg = (const char*)signs.p[k];
-            q[0] = *(const uint4_a8*)(sg + (m.x & kFwdCellMask));
-            q[1] = *(const uint4_a8*)(sg + (m.y & kFwdCellMask));
-            q[2] = *(const uint4_a8*)(sg + (m.z & kFwdCellMask));
-            q[3] = *(const uint4_a8*)(sg + (m.w & kFwdCellMask));
-        };
-        uint4 m1 = cur;
-        if (K > 1)
-            m1 = *(const uint4*)((const uint32_t*)dec_fwd.p[1] + pix);
-        uint4_a8 q0[PXT];
-        if (K > 0)
-            gather(0, cur, q0);
         int pending = 0;
         for (int k = 0; k < K; ++k)
         {
-            uint4 m2 = m1;
-            if (k + 2 < K)
-                m2 = *(const uint4*)((const uint32_t*)dec_fwd.p[k + 2] + pix);
-            uint4_a8 q1[PXT];
+            uint4 nxt = cur;
+            if (k + 1 < K)
+                nxt = *(const uint4*)((const uint32_t*)dec_fwd.p[k + 1] + pix);
+            const char* sg = (const char*)signs.p[k];
+            const uint32_t ev[PXT] = {cur.x, cur.y, cur.z, cur.w};
+            uint4_a8 qs[PXT];
 #pragma unroll
             for (int p = 0; p < PXT; ++p)
-                q1[p] = q0[p];
-            if (k + 1 < K)
-                gather(k + 1, m1, q1);
-            __builtin_amdgcn_sched_barrier(0); // the next frame's gathers are issued before this frame's are consumed
-            const uint32_t ev[PXT] = {cur.x, cur.y, cur.z, cur.w};
+                qs[p] = *(const uint4_a8*)(sg + (ev[p] & kFwdCellMask));
+            __builtin_amdgcn_sched_barrier(0); // all four gathers are in flight before the first is consumed
 #pragma unroll
             for (int p = 0; p < PXT; ++p)
             {
                 const uint32_t e = ev[p];
-                const uint4_a8 q = q0[p];
+                const uint4_a8 q = qs[p];
                 const char* le = lutb + ((e >> (kFwdLutShift - 4)) & 0x1F0u);
                 const uint4 wq = *(const uint4*)le;
-                // operands fit 24 bits: full-rate v_mad_u32_u24
                 uint32_t v = accv[p];
                 v += __umul24(q.x, wq.x);
                 v += __umul24(q.y, wq.y);
@@ -976,7 +992,6 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
             }
             if (++pending == fw.flush || k + 1 == K)
             {
-                // unpack the 10-bit fields before they can overflow
 #pragma unroll
                 for (int p = 0; p < PXT; ++p)
                 {
@@ -987,11 +1002,7 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
                 }
                 pending = 0;
             }
-            cur = m1;
-            m1 = m2;
-#pragma unroll
-            for (int p = 0; p < PXT; ++p)
-                q0[p] = q1[p];
+            cur = nxt;
         }
     }
     // ---- update
@@ -1109,6 +1120,14 @@ int launch_relative_motions(const PtrList& fwd, const MutPtrList& rel, int n, in
     return check_launch("relative_motions");
 }
 
+static int launch_group_maps(uint32_t* dec_bwd, size_t hr_px, hipStream_t st)
+{
+    const int bs = 256;
+    const size_t groups = hr_px / 4; // scale 4: every row is a whole number of groups
+    hipLaunchKernelGGL(k_group_maps, dim3((unsigned)((groups + bs - 1) / bs)), dim3(bs), 0, st, dec_bwd, groups);
+    return check_launch("group_maps");
+}
+
 int launch_build_maps(const float* rel, int rows, int cols, int scale, const CubicTables& t, int16_t* fwd_map,
                       int16_t* bwd_map, uint32_t* dec_fwd, uint32_t* dec_bwd, hipStream_t st)
 {
@@ -1120,7 +1139,9 @@ int launch_build_maps(const float* rel, int rows, int cols, int scale, const Cub
     const dim3 b(64, 4);
     hipLaunchKernelGGL(k_build_maps, grid2d(cols * scale, rows * scale, b), b, 0, st, rel, rows, cols, scale, t,
                        (short2*)fwd_map, (short2*)bwd_map, dec_fwd, dec_bwd);
-    return check_launch("build_maps");
+    if (int rc = check_launch("build_maps"))
+        return rc;
+    return dec_bwd ? launch_group_maps(dec_bwd, (size_t)rows * scale * cols * scale, st) : 0;
 }
 
 int launch_decode_maps(const int16_t* fwd_map, const int16_t* bwd_map, int hr_rows, int hr_cols, uint32_t* dec_fwd,
@@ -1129,7 +1150,9 @@ int launch_decode_maps(const int16_t* fwd_map, const int16_t* bwd_map, int hr_ro
     const dim3 b(64, 4);
     hipLaunchKernelGGL(k_decode_maps, grid2d(hr_cols, hr_rows, b), b, 0, st, (const short2*)fwd_map,
                        (const short2*)bwd_map, hr_rows, hr_cols, dec_fwd, dec_bwd);
-    return check_launch("decode_maps");
+    if (int rc = check_launch("decode_maps"))
+        return rc;
+    return dec_bwd ? launch_group_maps(dec_bwd, (size_t)hr_rows * hr_cols, st) : 0;
 }
 
 int launch_resize_cubic(const float* src, int srows, int scols, int ch, const CubicTables& t, float* dst, int drows,

@@ -244,7 +244,7 @@ int Solver::ensure(int K, int rows, int cols, int ch, int scale, hipStream_t st)
         {
             if (int rc = dec_fwd_[k].reserve(hr_px * 4))
                 return rc;
-            if (int rc = dec_bwd_[k].reserve(hr_px * 4))
+            if (int rc = dec_bwd_[k].reserve(dec_bwd_words(hr_px) * 4))
                 return rc;
         }
         if (signs_[k].capacity() < sign_bytes)

@@ -149,7 +149,7 @@ def set_kernel_path(path: int) -> None:
 
 
 def _solve(fn_name: str, sr, y: Sequence[torch.Tensor], motions: Sequence[torch.Tensor], base_idx: int,
-           return_full: bool):
+           return_full: bool, wait: bool = True):
     for t in y:
         _chk(t, torch.float32, "frame")
     for t in motions:
@@ -160,10 +160,12 @@ def _solve(fn_name: str, sr, y: Sequence[torch.Tensor], motions: Sequence[torch.
     out = torch.empty((rows * s - 2 * B, cols * s - 2 * B, ch), dtype=torch.float32, device=y[0].device)
     full = torch.empty((rows * s, cols * s, ch), dtype=torch.float32, device=y[0].device) if return_full else None
     fn = getattr(L.lib(), fn_name)
-    torch.cuda.synchronize()  # inputs were produced on torch's stream, the solve runs on the handle's
+    if wait:
+        torch.cuda.synchronize()  # inputs were produced on torch's stream, the solve runs on the handle's
     L.check(fn(sr.handle, L.ptr_array([t.data_ptr() for t in y3]), L.ptr_array([t.data_ptr() for t in motions]),
                len(y3), base_idx, rows, cols, ch, out.data_ptr(), full.data_ptr() if return_full else None))
-    sr.synchronize()
+    if wait:
+        sr.synchronize()
     if y[0].dim() == 2:
         out = out[:, :, 0]
         full = full[:, :, 0] if return_full else None
@@ -175,6 +177,10 @@ def run(sr, y, rel, base_idx: int, return_full: bool = False):
     return _solve("srx_run", sr, y, rel, base_idx, return_full)
 
 
-def process_device(sr, y, fwd_motions, base_idx: int, return_full: bool = False):
-    """BTV_L1_Base::process with forward motions (lib/src/btv_l1.cpp:328-355) on device tensors."""
-    return _solve("srx_process_device", sr, y, fwd_motions, base_idx, return_full)
+def process_device(sr, y, fwd_motions, base_idx: int, return_full: bool = False, wait: bool = True):
+    """BTV_L1_Base::process with forward motions (lib/src/btv_l1.cpp:328-355) on device tensors.
+
+    wait=False neither waits for torch's stream before the solve nor for the solve itself: the caller
+    makes sure the inputs are ready and calls sr.synchronize() before reading the result.
+    """
+    return _solve("srx_process_device", sr, y, fwd_motions, base_idx, return_full, wait)
