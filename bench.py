@@ -63,6 +63,24 @@ def algorithmic_bytes(P, C, K, s):
     return fwd, bwd
 
 
+def measured_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/*_traffic.json, written by
+    scripts/pmc_traffic.py on the same workload), or None."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", "*_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        for name, v in d["kernels"].items():
+            if name.startswith(kernel):
+                return v["traffic_bytes_per_launch"], os.path.relpath(files[-1], here)
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
+
+
 def cpu_baseline(args, lr_u8, flows, base):
     """The unfused restatement of the reference CPU path (oracle/, OpenMP over rows) on one window of the same
     workload, for a bounded number of iterations; scaled to the full iteration count."""
@@ -188,6 +206,8 @@ def main():
         bwd_launch_s = bwd_ms / max(n_it, 1) / 1e3
         fwd_launch_s = fwd_ms / max(n_it, 1) / 1e3
         achieved = bytes_bwd / bwd_launch_s / 1e9
+        default_workload = (args.rows, args.cols, args.channels, s, r) == (540, 960, 3, 4, 4)
+        traffic, traffic_src = measured_traffic("k_backproject_update_s4") if default_workload else (None, None)
         line = {
             "metric": "output Mpix/s, BTV-L1 4x 960x540->4K, 1/2/4/8 GPUs; % HBM roofline",
             "value": world * args.steps * mpix / elapsed,
@@ -218,7 +238,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_bwd,
                 "avg_launch_us": bwd_launch_s * 1e6,
                 "forward_kernel": {"algorithmic_bytes_per_launch": bytes_fwd, "avg_launch_us": fwd_launch_s * 1e6,

@@ -17,9 +17,10 @@ ap.add_argument("--K", type=int, default=9)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--lam", type=float, default=0.03)
+ap.add_argument("--shift", type=float, default=1.7, help="camera translation per frame, LR pixels")
 a = ap.parse_args()
 
-lr, flows, _ = synth.make_sequence(a.K, a.rows, a.cols, a.ch, a.scale, seed=1234, device="cuda")
+lr, flows, _ = synth.make_sequence(a.K, a.rows, a.cols, a.ch, a.scale, seed=1234, device="cuda", max_shift=a.shift)
 y = [f.to(torch.float32) for f in lr]
 sr = api.BTV_L1()
 sr.set("scale", a.scale)

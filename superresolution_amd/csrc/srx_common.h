@@ -62,7 +62,7 @@ int launch_relative_motions(const PtrList& fwd, const MutPtrList& rel, int n, in
 // dec_bwd holds dec_bwd_words(hr pixels) words (the map and its group map)
 inline size_t dec_bwd_words(size_t hr_px)
 {
-    return hr_px + hr_px / 4;
+    return hr_px + hr_px / 2;
 }
 int launch_build_maps(const float* rel, int rows, int cols, int scale, const CubicTables& t, int16_t* fwd_map,
                       int16_t* bwd_map, uint32_t* dec_fwd, uint32_t* dec_bwd, hipStream_t st);

@@ -18,10 +18,8 @@
 //                 specialised kernels:
 //                   backward: linear source pixel index, or rows*cols (the
 //                             zero pixel) when the source is outside; behind
-//                             the rows*cols entries follows the group map, one
-//                             word per 4 pixels of a row: the first entry of
-//                             the group, with bit 31 set when the four entries
-//                             are consecutive source pixels;
+//                             the rows*cols entries follows the group map, two
+//                             words per 4 pixels of a row (kGrp* below);
 //                   forward:  see kFwd* below.
 //   signs         one uint32 word per LR pixel and window frame: sign+1 (0,1,2)
 //                 of channel c in bits 10c..10c+1.  Generic kernels keep a
@@ -54,12 +52,19 @@ namespace
 //                left and top edges, which therefore need no entries of their
 //                own); 25 = all weights 0 (target outside the image, or in the
 //                last column / row, whose only tap is a reflected one)
+// group map entry of the backward map, for entries m0..m3 of 4 neighbouring pixels:
+//   word 0  bits 0..29 m0; bit 31: m1..m3 = m0+1..m0+3 (one run of source pixels);
+//           bit 30: some entry is further from the run than word 1 can say (use the full map)
+//   word 1  for i = 1..3, at bit 10(i-1): dx (5 bits, signed), then dy (5 bits, signed), with
+//           m_i = m0 + i + dx + dy * cols
+constexpr uint32_t kGrpRun = 1u << 31, kGrpFar = 1u << 30, kGrpIndexMask = (1u << 30) - 1;
 constexpr uint32_t kFwdCellMask = 0x00FFFFFFu;
 constexpr int kFwdLutShift = 24;
 constexpr uint32_t kFwdLutZero = 25;
 constexpr int kFwdLutSize = 26;
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 // volatile LDS vector access keeps 16-byte ds_read_b128 from being split into narrower reads
 typedef __attribute__((address_space(3))) const volatile v4i lds_cv4i;
 
@@ -211,14 +216,31 @@ __global__ void k_decode_maps(const short2* __restrict__ fwd_map, const short2* 
 }
 
 // group map behind the decoded backward map (layout at the top of this file)
-__global__ void k_group_maps(uint32_t* __restrict__ dec_bwd, size_t groups)
+__global__ void k_group_maps(uint32_t* __restrict__ dec_bwd, size_t groups, int W)
 {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= groups)
         return;
     const uint4 m = ((const uint4*)dec_bwd)[g];
-    const bool cons = m.y == m.x + 1 && m.z == m.x + 2 && m.w == m.x + 3;
-    dec_bwd[4 * groups + g] = m.x | (cons ? 0x80000000u : 0u);
+    const uint32_t mi[3] = {m.y, m.z, m.w};
+    uint32_t w0 = m.x, w1 = 0;
+    bool run = true, far = false;
+    for (int i = 1; i <= 3; ++i)
+    {
+        const int d = (int)(mi[i - 1] - m.x) - i; // distance from the run that starts at m0
+        run = run && d == 0;
+        // d = dy * W + dx with |dx|, |dy| <= 15 (unique once W > 30)
+        int dy = (abs(d) + W / 2) / W;
+        dy = d < 0 ? -dy : dy;
+        const int dx = d - dy * W;
+        far = far || W <= 30 || dx < -15 || dx > 15 || dy < -15 || dy > 15;
+        w1 |= ((uint32_t)(dx & 31) | ((uint32_t)(dy & 31) << 5)) << (10 * (i - 1));
+    }
+    if (run)
+        w0 |= kGrpRun;
+    else if (far)
+        w0 |= kGrpFar;
+    ((uint2*)(dec_bwd + 4 * groups))[g] = make_uint2(w0, w1);
 }
 
 // ps == 0: interleaved destination; otherwise planar with plane stride ps
@@ -587,7 +609,7 @@ template <int N> struct __attribute__((packed, aligned(4))) packed_floats
 #define SRX_A_ROWS 6
 #endif
 #ifndef SRX_A_WAVES
-#define SRX_A_WAVES 4
+#define SRX_A_WAVES 3
 #endif
 constexpr int kFwdRowsPerWave = SRX_A_ROWS;
 constexpr int kFwdStrip = 63;
@@ -615,47 +637,53 @@ __global__ __launch_bounds__(256, SRX_A_WAVES) void k_forward_sign_s4(const floa
     const bool first = x == 0;
 
     const uint32_t* map = (const uint32_t*)dec_bwd.p[k] + 4 * xl;      // full entries (lanes with a break only)
-    const uint32_t* grp = (const uint32_t*)dec_bwd.p[k] + (size_t)H * W + xl; // group map
+    const uint2* grp = (const uint2*)((const uint32_t*)dec_bwd.p[k] + (size_t)H * W) + xl; // group map
     const float* yk = (const float*)ys.p[k] + (size_t)xl * CH;
     uint32_t* sp = (uint32_t*)signs.p[k] + 2 * (size_t)xl;
     const float k0 = g.k[2], k1 = g.k[3], k2 = g.k[4];
 
     auto load_group = [&](int Y) { return grp[(size_t)reflect101(Y, H) * w]; };
-    auto consecutive = [](uint32_t gm) { return (gm >> 31) != 0; };
-    auto gather = [&](uint32_t gm, float4 (&a)[CH]) {
+    auto consecutive = [](const uint2& gm) { return (gm.x & kGrpRun) != 0; };
+    auto gather = [&](const uint2& gm, float4 (&a)[CH]) {
 #pragma unroll
         for (int c = 0; c < CH; ++c)
         {
-            const float4_a4 v = *(const float4_a4*)(X + c * ps + (gm & 0x7fffffffu));
+            const float4_a4 v = *(const float4_a4*)(X + c * ps + (gm.x & kGrpIndexMask));
             a[c] = make_float4(v.x, v.y, v.z, v.w);
         }
     };
-    // Entries that are not one run of consecutive pixels are usually two runs (one break): the
-    // pixels that do not continue the run from m.x are taken from a second gather that ends at
-    // m.w; what neither run covers is fetched pixel by pixel.
-    auto patch = [&](int Y, float4 (&a)[CH]) {
-        const uint4 m = *(const uint4*)(map + (size_t)reflect101(Y, H) * W);
-        const bool rok = m.w >= 3u;
-        const uint32_t rb = rok ? m.w - 3u : 0u;
-        const bool l1 = m.y == m.x + 1, l2 = m.z == m.x + 2, l3 = m.w == m.x + 3;
-        const bool r1 = rok && m.y == rb + 1, r2 = rok && m.z == rb + 2;
+    // Lanes whose entries are not one run fetch the other three pixels one by one.  The values land
+    // in registers of their own and are merged afterwards: a load into a register that an earlier
+    // load still has to fill would wait for that load, and the gathers of a row are meant to be in
+    // flight together.
+    auto patch_load = [&](const uint2& gm, int Y, float (&t)[CH][3]) {
+        uint4 m;
+        m.x = gm.x & kGrpIndexMask;
+        if (gm.x & kGrpFar)
+            m = *(const uint4*)(map + (size_t)reflect101(Y, H) * W);
+        else
+        {
+            const int w1 = (int)gm.y;
+            m.y = m.x + 1 + __builtin_amdgcn_sbfe(w1, 0, 5) + __builtin_amdgcn_sbfe(w1, 5, 5) * W;
+            m.z = m.x + 2 + __builtin_amdgcn_sbfe(w1, 10, 5) + __builtin_amdgcn_sbfe(w1, 15, 5) * W;
+            m.w = m.x + 3 + __builtin_amdgcn_sbfe(w1, 20, 5) + __builtin_amdgcn_sbfe(w1, 25, 5) * W;
+        }
 #pragma unroll
         for (int c = 0; c < CH; ++c)
         {
-            const packed_floats<3> v = *(const packed_floats<3>*)(X + c * ps + rb + 1);
-            a[c].y = l1 ? a[c].y : v.v[0];
-            a[c].z = l2 ? a[c].z : v.v[1];
-            a[c].w = l3 ? a[c].w : v.v[2];
+            t[c][0] = X[c * ps + m.y];
+            t[c][1] = X[c * ps + m.z];
+            t[c][2] = X[c * ps + m.w];
         }
-        if (!((l1 || r1) && (l2 || r2) && (l3 || rok)))
-        {
+    };
+    auto patch_merge = [&](const uint2& gm, const float (&t)[CH][3], float4 (&a)[CH]) {
+        const bool run = consecutive(gm);
 #pragma unroll
-            for (int c = 0; c < CH; ++c)
-            {
-                a[c].y = X[c * ps + m.y];
-                a[c].z = X[c * ps + m.z];
-                a[c].w = X[c * ps + m.w];
-            }
+        for (int c = 0; c < CH; ++c)
+        {
+            a[c].y = run ? a[c].y : t[c][0];
+            a[c].z = run ? a[c].z : t[c][1];
+            a[c].w = run ? a[c].w : t[c][2];
         }
     };
     auto row_pass = [&](const float4 (&a)[CH], float (&out)[CH]) {
@@ -673,21 +701,23 @@ __global__ __launch_bounds__(256, SRX_A_WAVES) void k_forward_sign_s4(const floa
     };
 
     float rr[5][CH];
-    uint32_t mc[4];
+    uint2 mc[4];
     {
-        const uint32_t m0 = load_group(4 * y0 - 2);
+        const uint2 m0 = load_group(4 * y0 - 2);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             mc[r] = load_group(4 * y0 - 1 + r);
         float4 a[CH];
+        float t[CH][3] = {};
         gather(m0, a);
         if (!consecutive(m0))
-            patch(4 * y0 - 2, a);
+            patch_load(m0, 4 * y0 - 2, t);
+        patch_merge(m0, t, a);
         row_pass(a, rr[0]);
     }
     for (int y = y0; y < y1; ++y)
     {
-        uint32_t mn[4];
+        uint2 mn[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             mn[r] = mc[r];
@@ -706,6 +736,7 @@ __global__ __launch_bounds__(256, SRX_A_WAVES) void k_forward_sign_s4(const floa
         }
 
         float4 a[4][CH];
+        float t[4][CH][3] = {};
         bool broken = false;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -718,8 +749,11 @@ __global__ __launch_bounds__(256, SRX_A_WAVES) void k_forward_sign_s4(const floa
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (!consecutive(mc[r]))
-                    patch(4 * y - 1 + r, a[r]);
+                    patch_load(mc[r], 4 * y - 1 + r, t[r]);
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            patch_merge(mc[r], t[r], a[r]);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             row_pass(a[r], rr[r + 1]);
@@ -766,6 +800,10 @@ struct __attribute__((packed, aligned(8))) uint4_a8
     uint32_t x, y, z, w;
 };
 
+#ifndef SRX_B_FSUB
+#define SRX_B_FSUB 1
+#endif
+#if !SRX_B_FSUB
 // order-preserving float <-> int key (an involution); -0 is folded into +0 so
 // that integer order equals float order for all non-NaN values
 __device__ __forceinline__ int float_key(float x)
@@ -777,7 +815,28 @@ __device__ __forceinline__ float key_float(int k)
 {
     return __int_as_float(k ^ ((k >> 31) & 0x7fffffff));
 }
+#endif
 // sign(a - b) for keys: saturating subtract, then clamp to [-1, 1]
+#if SRX_B_FSUB
+// keys are the float bits themselves (-0 folded into +0): a - b is +0 exactly when a == b and has the
+// sign of the comparison otherwise (subnormal differences are kept), so its bit pattern, read as an
+// integer and clamped to [-1, 1], is sign(a - b)
+__device__ __forceinline__ int float_key(float x)
+{
+    return __float_as_int(x + 0.0f);
+}
+__device__ __forceinline__ float key_float(int k)
+{
+    return __int_as_float(k);
+}
+__device__ __forceinline__ int key_sign(int a, int b)
+{
+    int s;
+    const float t = __int_as_float(a) - __int_as_float(b);
+    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(s) : "v"(__float_as_int(t)));
+    return s;
+}
+#else
 __device__ __forceinline__ int key_sign(int a, int b)
 {
     int d, s;
@@ -785,6 +844,7 @@ __device__ __forceinline__ int key_sign(int a, int b)
     asm("v_med3_i32 %0, %1, -1, 1" : "=v"(s) : "v"(d));
     return s;
 }
+#endif
 
 // Back-projection of all K frames + BTV regulariser + update for one 64x16 tile
 // of HR pixels per block; each thread owns 4 consecutive pixels of one row.
@@ -809,6 +869,9 @@ __device__ __forceinline__ int key_sign(int a, int b)
 #ifndef SRX_B_WAVES
 #define SRX_B_WAVES 5
 #endif
+#ifndef SRX_B_PARK
+#define SRX_B_PARK 1
+#endif
 template <int CH>
 __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
     const float* __restrict__ X, float* __restrict__ X_out, int H, int W, size_t ps, PtrList dec_fwd,
@@ -823,7 +886,11 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
     constexpr int NV = 3;               // vectors per window row: columns [4tx, 4tx+12) of the LDS row
     __shared__ __attribute__((aligned(16))) int tile[CH * LROWS * PITCH];
     __shared__ uint4 lut[2 * kFwdLutSize]; // [li] = weights, [kFwdLutSize + li].x = their sum
+#if SRX_B_PARK
     __shared__ float park[CH * PXT * 256];  // regulariser values rest here while the frame loop runs
+#else
+    float park[CH * PXT];
+#endif
 
     const unsigned t = xcd_contiguous(blockIdx.x, n_tiles);
     if (t >= n_tiles)
@@ -930,6 +997,51 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
                     if (m == 0 && l == 0)
                         continue; // both signs compare the pixel with itself: adds w * 0
                     const float wt = bw.w[ind];
+#if SRX_B_FSUB
+                    // differences two at a time (v_pk_add_f32) where the window registers pair up:
+                    // pixels (0,1),(2,3) for even l, pixels (1,2) for odd l
+                    const float* pf = (const float*)pv;
+                    const float* mf = (const float*)mv;
+                    const float* cf = (const float*)cv;
+                    float tp[PXT], tm[PXT];
+                    constexpr int E0 = 0;
+                    if ((l & 1) == 0)
+                    {
+#pragma unroll
+                        for (int e = E0; e < PXT; e += 2)
+                        {
+                            const v2f c2 = *(const v2f*)&cf[HL + e];
+                            const v2f a = c2 - *(const v2f*)&pf[HL + e + l];
+                            const v2f b = c2 - *(const v2f*)&mf[HL + e - l];
+                            tp[e] = a.x, tp[e + 1] = a.y, tm[e] = b.x, tm[e + 1] = b.y;
+                        }
+                    }
+                    else
+                    {
+                        const v2f c2 = v2f{cf[HL + 1], cf[HL + 2]};
+                        const v2f a = c2 - *(const v2f*)&pf[HL + 1 + l];
+                        const v2f b = c2 - *(const v2f*)&mf[HL + 1 - l];
+                        tp[1] = a.x, tp[2] = a.y, tm[1] = b.x, tm[2] = b.y;
+                        tp[0] = cf[HL] - pf[HL + l], tm[0] = cf[HL] - mf[HL - l];
+                        tp[3] = cf[HL + 3] - pf[HL + 3 + l], tm[3] = cf[HL + 3] - mf[HL + 3 - l];
+                    }
+                    float df[PXT];
+#pragma unroll
+                    for (int e = 0; e < PXT; ++e)
+                    {
+                        int s1, s2;
+                        asm("v_med3_i32 %0, %1, -1, 1" : "=v"(s1) : "v"(__float_as_int(tp[e])));
+                        asm("v_med3_i32 %0, %1, -1, 1" : "=v"(s2) : "v"(__float_as_int(tm[e])));
+                        df[e] = (float)(s1 + s2);
+                    }
+                    // w * d is exact (d in -2..2), so the fused form rounds once, like acc += w * d
+#pragma unroll
+                    for (int e = 0; e < PXT; e += 2)
+                    {
+                        const v2f r = __builtin_elementwise_fma(v2f{wt, wt}, v2f{df[e], df[e + 1]}, v2f{reg[e], reg[e + 1]});
+                        reg[e] = r.x, reg[e + 1] = r.y;
+                    }
+#else
 #pragma unroll
                     for (int e = 0; e < PXT; ++e)
                     {
@@ -937,11 +1049,12 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
                         // w * d is exact (d in -2..2), so the fused form rounds once, like acc += w * d
                         reg[e] = __builtin_fmaf(wt, (float)d, reg[e]);
                     }
+#endif
                 }
             }
 #pragma unroll
             for (int e = 0; e < PXT; ++e)
-                park[(c * PXT + e) * 256 + tid] = reg[e];
+                park[SRX_B_PARK ? (c * PXT + e) * 256 + tid : c * PXT + e] = reg[e];
         }
     }
 
@@ -1021,7 +1134,7 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
             float d = (float)(acc[p][c] - bias[p]) * 0.00390625f;
             if (lambda > 0)
             {
-                const float rg = interior ? park[(c * PXT + p) * 256 + tid] : 0.0f;
+                const float rg = interior ? park[SRX_B_PARK ? (c * PXT + p) * 256 + tid : c * PXT + p] : 0.0f;
                 d = (float)((double)d + (double)rg * (-lambda));
             }
             outv[p] = (float)((double)key_float(ctr[p]) + (double)d * tau);
@@ -1120,11 +1233,11 @@ int launch_relative_motions(const PtrList& fwd, const MutPtrList& rel, int n, in
     return check_launch("relative_motions");
 }
 
-static int launch_group_maps(uint32_t* dec_bwd, size_t hr_px, hipStream_t st)
+static int launch_group_maps(uint32_t* dec_bwd, size_t hr_px, int hr_cols, hipStream_t st)
 {
     const int bs = 256;
     const size_t groups = hr_px / 4; // scale 4: every row is a whole number of groups
-    hipLaunchKernelGGL(k_group_maps, dim3((unsigned)((groups + bs - 1) / bs)), dim3(bs), 0, st, dec_bwd, groups);
+    hipLaunchKernelGGL(k_group_maps, dim3((unsigned)((groups + bs - 1) / bs)), dim3(bs), 0, st, dec_bwd, groups, hr_cols);
     return check_launch("group_maps");
 }
 
@@ -1141,7 +1254,7 @@ int launch_build_maps(const float* rel, int rows, int cols, int scale, const Cub
                        (short2*)fwd_map, (short2*)bwd_map, dec_fwd, dec_bwd);
     if (int rc = check_launch("build_maps"))
         return rc;
-    return dec_bwd ? launch_group_maps(dec_bwd, (size_t)rows * scale * cols * scale, st) : 0;
+    return dec_bwd ? launch_group_maps(dec_bwd, (size_t)rows * scale * cols * scale, cols * scale, st) : 0;
 }
 
 int launch_decode_maps(const int16_t* fwd_map, const int16_t* bwd_map, int hr_rows, int hr_cols, uint32_t* dec_fwd,
@@ -1152,7 +1265,7 @@ int launch_decode_maps(const int16_t* fwd_map, const int16_t* bwd_map, int hr_ro
                        (const short2*)bwd_map, hr_rows, hr_cols, dec_fwd, dec_bwd);
     if (int rc = check_launch("decode_maps"))
         return rc;
-    return dec_bwd ? launch_group_maps(dec_bwd, (size_t)hr_rows * hr_cols, st) : 0;
+    return dec_bwd ? launch_group_maps(dec_bwd, (size_t)hr_rows * hr_cols, hr_cols, st) : 0;
 }
 
 int launch_resize_cubic(const float* src, int srows, int scols, int ch, const CubicTables& t, float* dst, int drows,
