@@ -800,61 +800,30 @@ struct __attribute__((packed, aligned(8))) uint4_a8
     uint32_t x, y, z, w;
 };
 
-#ifndef SRX_B_FSUB
-#define SRX_B_FSUB 1
-#endif
-#if !SRX_B_FSUB
-// order-preserving float <-> int key (an involution); -0 is folded into +0 so
-// that integer order equals float order for all non-NaN values
-__device__ __forceinline__ int float_key(float x)
+// The BTV tile holds the pixels as floats with -0 folded into +0.  Then a - b is +0 exactly when
+// a == b and has the sign of the comparison otherwise (subnormal differences are kept: the kernels
+// run with fp32 denormals on), so the bit pattern of the difference, read as an integer and clamped
+// to [-1, 1], is sign(a - b).
+__device__ __forceinline__ float fold_zero(float x)
 {
-    const int b = __float_as_int(x + 0.0f);
-    return b ^ ((b >> 31) & 0x7fffffff);
+    return x + 0.0f;
 }
-__device__ __forceinline__ float key_float(int k)
-{
-    return __int_as_float(k ^ ((k >> 31) & 0x7fffffff));
-}
-#endif
-// sign(a - b) for keys: saturating subtract, then clamp to [-1, 1]
-#if SRX_B_FSUB
-// keys are the float bits themselves (-0 folded into +0): a - b is +0 exactly when a == b and has the
-// sign of the comparison otherwise (subnormal differences are kept), so its bit pattern, read as an
-// integer and clamped to [-1, 1], is sign(a - b)
-__device__ __forceinline__ int float_key(float x)
-{
-    return __float_as_int(x + 0.0f);
-}
-__device__ __forceinline__ float key_float(int k)
-{
-    return __int_as_float(k);
-}
-__device__ __forceinline__ int key_sign(int a, int b)
+__device__ __forceinline__ int sign_of_difference(float t)
 {
     int s;
-    const float t = __int_as_float(a) - __int_as_float(b);
     asm("v_med3_i32 %0, %1, -1, 1" : "=v"(s) : "v"(__float_as_int(t)));
     return s;
 }
-#else
-__device__ __forceinline__ int key_sign(int a, int b)
-{
-    int d, s;
-    asm("v_sub_i32 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
-    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(s) : "v"(d));
-    return s;
-}
-#endif
 
 // Back-projection of all K frames + BTV regulariser + update for one 64x16 tile
 // of HR pixels per block; each thread owns 4 consecutive pixels of one row.
 // X and X_out are planar.
-//  * BTV: the tile of X (+3 px halo) sits in LDS, one plane per channel, as
-//    order-preserving integer keys; sign(a-b) is a saturating subtract and a
-//    clamp; accumulation order is the reference's (lib/src/btv_l1.cpp:221-233).
-//    Channels are processed one after the other, which keeps the register
-//    windows small.  NaN pixels are ordered as large values instead of
-//    comparing unordered.
+//  * BTV: the tile of X (+3 px halo) sits in LDS, one plane per channel;
+//    sign(a-b) is a float subtract (two at a time where the window registers
+//    pair up) and an integer clamp; accumulation order is the reference's
+//    (lib/src/btv_l1.cpp:221-233).  Channels are processed one after the other,
+//    which keeps the register windows small; the results rest in LDS while the
+//    frame loop runs.  NaN - x counts as +1 instead of comparing unordered.
 //  * per frame: one 16-byte load of 4 decoded forward-map entries (fetched one
 //    frame ahead), then per pixel one 16-byte read of the 2x2 block of sign
 //    cells from the pair plane, times the entry's integer weights.  A sign word
@@ -869,9 +838,6 @@ __device__ __forceinline__ int key_sign(int a, int b)
 #ifndef SRX_B_WAVES
 #define SRX_B_WAVES 5
 #endif
-#ifndef SRX_B_PARK
-#define SRX_B_PARK 1
-#endif
 template <int CH>
 __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
     const float* __restrict__ X, float* __restrict__ X_out, int H, int W, size_t ps, PtrList dec_fwd,
@@ -884,13 +850,9 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
     constexpr int LROWS = TYN + 2 * HALO;
     constexpr int RV = PITCH / 4;       // 16-byte vectors per LDS row
     constexpr int NV = 3;               // vectors per window row: columns [4tx, 4tx+12) of the LDS row
-    __shared__ __attribute__((aligned(16))) int tile[CH * LROWS * PITCH];
+    __shared__ __attribute__((aligned(16))) float tile[CH * LROWS * PITCH];
     __shared__ uint4 lut[2 * kFwdLutSize]; // [li] = weights, [kFwdLutSize + li].x = their sum
-#if SRX_B_PARK
     __shared__ float park[CH * PXT * 256];  // regulariser values rest here while the frame loop runs
-#else
-    float park[CH * PXT];
-#endif
 
     const unsigned t = xcd_contiguous(blockIdx.x, n_tiles);
     if (t >= n_tiles)
@@ -948,9 +910,9 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
             if (idx < NCH)
             {
                 const float4 v = stage[it];
-                // outside the image the tile holds key(0); those cells are never read by an interior pixel
-                *(v4i*)&tile[4 * idx] = in ? v4i{float_key(v.x), float_key(v.y), float_key(v.z), float_key(v.w)}
-                                           : v4i{0, 0, 0, 0};
+                // outside the image the tile holds 0; those cells are never read by an interior pixel
+                *(float4*)&tile[4 * idx] = in ? make_float4(fold_zero(v.x), fold_zero(v.y), fold_zero(v.z), fold_zero(v.w))
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     }
@@ -968,15 +930,11 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
 #pragma unroll
             for (int v = 0; v < NV; ++v)
                 cv[v] = tp[v];
-            const int* cw = (const int*)cv;
-            int ctr[PXT];
+            const float* cf = (const float*)cv;
             float reg[PXT];
 #pragma unroll
             for (int e = 0; e < PXT; ++e)
-            {
-                ctr[e] = cw[HL + e];
                 reg[e] = 0.0f;
-            }
 
             int ind = 0;
 #pragma unroll
@@ -989,31 +947,26 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
                     pv[v] = m == 0 ? cv[v] : tp[m * RV + v];
                     mv[v] = m == 0 ? cv[v] : tp[-m * RV + v];
                 }
-                const int* pw = (const int*)pv;
-                const int* mw = (const int*)mv;
+                const float* pf = (const float*)pv;
+                const float* mf = (const float*)mv;
 #pragma unroll
                 for (int l = 3; l + m >= 0; --l, ++ind)
                 {
                     if (m == 0 && l == 0)
                         continue; // both signs compare the pixel with itself: adds w * 0
                     const float wt = bw.w[ind];
-#if SRX_B_FSUB
                     // differences two at a time (v_pk_add_f32) where the window registers pair up:
                     // pixels (0,1),(2,3) for even l, pixels (1,2) for odd l
-                    const float* pf = (const float*)pv;
-                    const float* mf = (const float*)mv;
-                    const float* cf = (const float*)cv;
-                    float tp[PXT], tm[PXT];
-                    constexpr int E0 = 0;
+                    float dp[PXT], dm[PXT];
                     if ((l & 1) == 0)
                     {
 #pragma unroll
-                        for (int e = E0; e < PXT; e += 2)
+                        for (int e = 0; e < PXT; e += 2)
                         {
                             const v2f c2 = *(const v2f*)&cf[HL + e];
                             const v2f a = c2 - *(const v2f*)&pf[HL + e + l];
                             const v2f b = c2 - *(const v2f*)&mf[HL + e - l];
-                            tp[e] = a.x, tp[e + 1] = a.y, tm[e] = b.x, tm[e + 1] = b.y;
+                            dp[e] = a.x, dp[e + 1] = a.y, dm[e] = b.x, dm[e + 1] = b.y;
                         }
                     }
                     else
@@ -1021,40 +974,27 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
                         const v2f c2 = v2f{cf[HL + 1], cf[HL + 2]};
                         const v2f a = c2 - *(const v2f*)&pf[HL + 1 + l];
                         const v2f b = c2 - *(const v2f*)&mf[HL + 1 - l];
-                        tp[1] = a.x, tp[2] = a.y, tm[1] = b.x, tm[2] = b.y;
-                        tp[0] = cf[HL] - pf[HL + l], tm[0] = cf[HL] - mf[HL - l];
-                        tp[3] = cf[HL + 3] - pf[HL + 3 + l], tm[3] = cf[HL + 3] - mf[HL + 3 - l];
+                        dp[1] = a.x, dp[2] = a.y, dm[1] = b.x, dm[2] = b.y;
+                        dp[0] = cf[HL] - pf[HL + l], dm[0] = cf[HL] - mf[HL - l];
+                        dp[3] = cf[HL + 3] - pf[HL + 3 + l], dm[3] = cf[HL + 3] - mf[HL + 3 - l];
                     }
                     float df[PXT];
 #pragma unroll
                     for (int e = 0; e < PXT; ++e)
-                    {
-                        int s1, s2;
-                        asm("v_med3_i32 %0, %1, -1, 1" : "=v"(s1) : "v"(__float_as_int(tp[e])));
-                        asm("v_med3_i32 %0, %1, -1, 1" : "=v"(s2) : "v"(__float_as_int(tm[e])));
-                        df[e] = (float)(s1 + s2);
-                    }
+                        df[e] = (float)(sign_of_difference(dp[e]) + sign_of_difference(dm[e]));
                     // w * d is exact (d in -2..2), so the fused form rounds once, like acc += w * d
 #pragma unroll
                     for (int e = 0; e < PXT; e += 2)
                     {
-                        const v2f r = __builtin_elementwise_fma(v2f{wt, wt}, v2f{df[e], df[e + 1]}, v2f{reg[e], reg[e + 1]});
+                        const v2f r = __builtin_elementwise_fma(v2f{wt, wt}, v2f{df[e], df[e + 1]},
+                                                                v2f{reg[e], reg[e + 1]});
                         reg[e] = r.x, reg[e + 1] = r.y;
                     }
-#else
-#pragma unroll
-                    for (int e = 0; e < PXT; ++e)
-                    {
-                        const int d = key_sign(ctr[e], pw[HL + e + l]) + key_sign(ctr[e], mw[HL + e - l]);
-                        // w * d is exact (d in -2..2), so the fused form rounds once, like acc += w * d
-                        reg[e] = __builtin_fmaf(wt, (float)d, reg[e]);
-                    }
-#endif
                 }
             }
 #pragma unroll
             for (int e = 0; e < PXT; ++e)
-                park[SRX_B_PARK ? (c * PXT + e) * 256 + tid : c * PXT + e] = reg[e];
+                park[(c * PXT + e) * 256 + tid] = reg[e];
         }
     }
 
@@ -1134,10 +1074,10 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
             float d = (float)(acc[p][c] - bias[p]) * 0.00390625f;
             if (lambda > 0)
             {
-                const float rg = interior ? park[SRX_B_PARK ? (c * PXT + p) * 256 + tid : c * PXT + p] : 0.0f;
+                const float rg = interior ? park[(c * PXT + p) * 256 + tid] : 0.0f;
                 d = (float)((double)d + (double)rg * (-lambda));
             }
-            outv[p] = (float)((double)key_float(ctr[p]) + (double)d * tau);
+            outv[p] = (float)((double)__int_as_float(ctr[p]) + (double)d * tau);
         }
         *(float4*)(X_out + c * ps + pix) = make_float4(outv[0], outv[1], outv[2], outv[3]);
     }
