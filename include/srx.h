@@ -231,6 +231,25 @@ SRX_API int srx_get_kernel_path(void);
 SRX_API int srx_k_crop_convert(const float* X, int rows, int cols, int ch, int border, void* dst, int depth,
                                void* stream);
 
+/* Quality metrics of the reference's quality harness, computed on the GPU with
+ * wavefront reductions.  Images: same size, depth and channel count (1..4),
+ * host or device memory, any row pitch (a region of interest is passed as data
+ * pointer + step, like goldFrame(inner) at samples/quality_test/main.cpp:320).
+ * The calls return when the result is on the host; `stream` orders them after
+ * earlier work on that stream.
+ *  srx_quality_psnr   cv::PSNR as called at samples/quality_test/main.cpp:320,323
+ *                     (8-bit images only): 20 log10(255 / (rms + DBL_EPSILON)).
+ *  srx_quality_mssim  MSSIM() of samples/quality_test/main.cpp:140-199: 11x11
+ *                     Gaussian (sigma 1.5) SSIM map, C1 = 6.5025, C2 = 58.5225,
+ *                     averaged.  per_channel (4 doubles, may be NULL) receives
+ *                     the mean of every channel's map; *mssim (may be NULL) the
+ *                     value the reference's function returns: mean[0] for one
+ *                     channel, else (mean[0] + mean[1] + mean[3]) / 3 -- the
+ *                     reference reads component 3 where 2 is meant (:198). */
+SRX_API int srx_quality_psnr(const srx_image* a, const srx_image* b, double* psnr, void* stream);
+SRX_API int srx_quality_mssim(const srx_image* a, const srx_image* b, double* per_channel, double* mssim,
+                              void* stream);
+
 /* BTV_L1_Base::run, lib/src/btv_l1.cpp:357-457, on device-resident inputs
  * with the handle's parameters.  y_host / rel_host: host arrays of K device
  * pointers (float LR frames rows x cols x ch; relative motions rows x cols x

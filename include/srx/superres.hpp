@@ -71,6 +71,19 @@ class Mat
     size_t step() const { return im_.step ? im_.step : (size_t)im_.cols * im_.channels * (im_.depth == SRX_8U ? 1 : 4); }
     template <typename T> T* ptr(int y = 0) const { return (T*)((uint8_t*)im_.data + (size_t)y * step()); }
     const srx_image& view() const { return im_; }
+    // borrowed view of a rectangle, like cv::Mat::operator()(Rect); shares this Mat's memory
+    Mat roi(int x, int y, int width, int height) const
+    {
+        if (x < 0 || y < 0 || width < 1 || height < 1 || x + width > im_.cols || y + height > im_.rows)
+            throw Exception(SRX_ERR_INVALID, "Mat::roi: rectangle outside the image");
+        Mat m;
+        m.own_ = own_;
+        m.im_ = im_;
+        m.im_.step = step();
+        m.im_.data = (uint8_t*)im_.data + (size_t)y * step() + (size_t)x * im_.channels * (im_.depth == SRX_8U ? 1 : 4);
+        m.im_.rows = height, m.im_.cols = width;
+        return m;
+    }
     // deep copy of a host image (the frame returned by nextFrame() aliases an internal buffer)
     Mat clone() const
     {
@@ -88,6 +101,23 @@ class Mat
     srx_image im_{};
     std::shared_ptr<std::vector<uint8_t>> own_;
 };
+
+// The two metrics of the reference's quality harness, computed on the GPU.
+// cv::PSNR as called at samples/quality_test/main.cpp:320,323 (8-bit images)
+inline double PSNR(const Mat& a, const Mat& b)
+{
+    double v = 0;
+    check(srx_quality_psnr(&a.view(), &b.view(), &v, nullptr));
+    return v;
+}
+// MSSIM() of samples/quality_test/main.cpp:140-199; returns what that function returns (for colour
+// images (m0 + m1 + m3) / 3, see srx.h).  per_channel, if given, receives the 4 channel means.
+inline double MSSIM(const Mat& a, const Mat& b, double* per_channel = nullptr)
+{
+    double v = 0;
+    check(srx_quality_mssim(&a.view(), &b.view(), per_channel, &v, nullptr));
+    return v;
+}
 
 // videostab::IFrameSource as the reference uses it (samples/quality_test/main.cpp:43-50)
 class IFrameSource
@@ -139,12 +169,26 @@ inline Ptr<DenseOpticalFlow> createOptFlow_DualTVL1()
     return std::make_shared<DualTVL1>();
 }
 
+// The part of cv::Algorithm that the reference's programs use on a Ptr<SuperResolution>
+// (samples/quality_test/main.cpp:261-267): parameters by name.
+class Algorithm
+{
+  public:
+    virtual ~Algorithm() {}
+    virtual void set(const std::string& name, int v) = 0;
+    virtual void set(const std::string& name, double v) = 0;
+    virtual void set(const std::string& name, const Ptr<DenseOpticalFlow>& flow) = 0;
+    virtual int getInt(const std::string& name) const = 0;
+    virtual double getDouble(const std::string& name) const = 0;
+};
+
 // lib/include/super_resolution.hpp:146-163
-class SuperResolution : public IFrameSource
+class SuperResolution : public Algorithm, public IFrameSource
 {
   public:
     virtual ~SuperResolution() {}
     virtual void setFrameSource(const Ptr<IFrameSource>& frameSource) = 0;
+    virtual void setOpticalFlow(const Ptr<DenseOpticalFlow>& flow) = 0;
 };
 
 // SuperResolution.BTV_L1 (lib/include/super_resolution.hpp:165-195)
@@ -158,21 +202,21 @@ class BTV_L1 : public SuperResolution
     BTV_L1& operator=(const BTV_L1&) = delete;
 
     // ---- Algorithm::set / get with the names of lib/src/super_resolution.cpp:83-93
-    void set(const std::string& name, int v) { check(srx_set_int(h_, name.c_str(), v)); }
-    void set(const std::string& name, double v) { check(srx_set_double(h_, name.c_str(), v)); }
-    void set(const std::string& name, const Ptr<DenseOpticalFlow>& flow)
+    void set(const std::string& name, int v) override { check(srx_set_int(h_, name.c_str(), v)); }
+    void set(const std::string& name, double v) override { check(srx_set_double(h_, name.c_str(), v)); }
+    void set(const std::string& name, const Ptr<DenseOpticalFlow>& flow) override
     {
         if (name != "opticalFlow")
             throw Exception(SRX_ERR_INVALID, "unknown algorithm parameter: " + name);
         setOpticalFlow(flow);
     }
-    int getInt(const std::string& name) const
+    int getInt(const std::string& name) const override
     {
         int v = 0;
         check(srx_get_int(h_, name.c_str(), &v));
         return v;
     }
-    double getDouble(const std::string& name) const
+    double getDouble(const std::string& name) const override
     {
         double v = 0;
         check(srx_get_double(h_, name.c_str(), &v));
@@ -201,7 +245,7 @@ class BTV_L1 : public SuperResolution
     int getTemporalAreaRadius() const { return getInt("temporalAreaRadius"); }
     void setTemporalAreaRadius(int v) { set("temporalAreaRadius", v); }
 
-    void setOpticalFlow(const Ptr<DenseOpticalFlow>& flow)
+    void setOpticalFlow(const Ptr<DenseOpticalFlow>& flow) override
     {
         flow_ = flow;
         if (!flow)

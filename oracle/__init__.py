@@ -296,3 +296,31 @@ def _solve(fn, y, motions, base_idx, params, return_full):
         out = out[:, :, 0]
         full = full[:, :, 0] if return_full else None
     return (out, full) if return_full else out
+
+
+# ---------------------------------------------------------------------------
+# quality metrics (oracle/quality_oracle.c)
+def psnr_8u(a: np.ndarray, b: np.ndarray) -> float:
+    """cv::PSNR of two 8-bit images (rows, cols[, ch]); row pitches are honoured, so views work."""
+    L = lib()
+    L.orc_psnr_8u.restype = C.c_double
+    L.orc_psnr_8u.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]
+    assert a.dtype == np.uint8 and b.dtype == np.uint8 and a.shape == b.shape
+    ch = a.shape[2] if a.ndim == 3 else 1
+    for im in (a, b):  # rows may be strided, pixels within a row are dense
+        assert im.strides[1] == ch and (im.ndim == 2 or im.strides[2] == 1)
+    return L.orc_psnr_8u(a.ctypes.data, a.strides[0], b.ctypes.data, b.strides[0], a.shape[0], a.shape[1], ch)
+
+
+def mssim(a: np.ndarray, b: np.ndarray):
+    """MSSIM of samples/quality_test/main.cpp:140-199.  Returns (value as the reference returns it,
+    per-channel means of the SSIM map)."""
+    L = lib()
+    L.orc_mssim.restype = C.c_double
+    L.orc_mssim.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    a3 = np.ascontiguousarray(a if a.ndim == 3 else a[:, :, None], dtype=np.float32)
+    b3 = np.ascontiguousarray(b if b.ndim == 3 else b[:, :, None], dtype=np.float32)
+    assert a3.shape == b3.shape
+    m = (C.c_double * 4)()
+    v = L.orc_mssim(a3.ctypes.data_as(_fp), b3.ctypes.data_as(_fp), a3.shape[0], a3.shape[1], a3.shape[2], m)
+    return v, np.array(m[:a3.shape[2]])

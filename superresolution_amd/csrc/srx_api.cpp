@@ -1204,6 +1204,26 @@ SRX_API int srx_k_backproject_update(const float* X, float* X_out, int hr_rows, 
                                      st);
 }
 
+SRX_API int srx_quality_psnr(const srx_image* a, const srx_image* b, double* psnr, void* stream)
+{
+    if (!a || !b || !psnr)
+    {
+        set_error("srx_quality_psnr: NULL argument");
+        return SRX_ERR_INVALID;
+    }
+    return quality_psnr(*a, *b, psnr, (hipStream_t)stream);
+}
+
+SRX_API int srx_quality_mssim(const srx_image* a, const srx_image* b, double* per_channel, double* mssim, void* stream)
+{
+    if (!a || !b || (!per_channel && !mssim))
+    {
+        set_error("srx_quality_mssim: NULL argument");
+        return SRX_ERR_INVALID;
+    }
+    return quality_mssim(*a, *b, per_channel, mssim, (hipStream_t)stream);
+}
+
 SRX_API int srx_set_kernel_path(int path)
 {
     if (path != 0 && path != 1)

@@ -81,6 +81,11 @@ extern int g_kernel_path;
 // Validates what the reference only debug-asserts (lib/src/btv_l1.cpp:359-365).
 int validate_params(const Params& p);
 
+// Quality metrics (srx_quality.hip): cv::PSNR and the MSSIM of samples/quality_test/main.cpp:140-199.
+// Images may live in host or device memory; the calls return when the result is on the host.
+int quality_psnr(const srx_image& a, const srx_image& b, double* psnr, hipStream_t st);
+int quality_mssim(const srx_image& a, const srx_image& b, double* per_channel, double* mssim, hipStream_t st);
+
 // Host-built cv::resize(INTER_CUBIC) tap tables
 void cubic_table_x(int scols, int dcols, std::vector<int>& sx, std::vector<float>& alpha);
 void cubic_table_y(int srows, int drows, std::vector<int>& sy, std::vector<float>& beta);

@@ -868,7 +868,6 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
         tx = pos;
         ty = (tid >> 6) * 4 + ((tid >> 5) & 1) * 2 + grp;
     }
-    const int w = W >> 2;
     const int i = min(i0 + ty, H - 1), j = min(j0 + tx * PXT, W - PXT); // clamped; stores are masked below
     const bool live = (i0 + ty) < H && (j0 + tx * PXT) < W; // W is a multiple of 4: a thread's pixels are all in or all out
     const size_t pix = (size_t)i * W + j;

@@ -1,0 +1,25 @@
+"""Runs the C++ quality harness (samples/quality_harness.cpp: the measurement loop of the reference's
+samples/quality_test/main.cpp:269-358 on the C++ facade) on a small synthetic clip.  The program is
+built beforehand by __graft_entry__.build() (samples/Makefile)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "samples", "bin", "quality_harness")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels", [1, 3])
+def test_super_resolution_beats_bicubic(channels):
+    assert os.path.exists(EXE), "samples/bin/quality_harness is missing: run __graft_entry__.build()"
+    r = subprocess.run([EXE, "--rows", "128", "--cols", "160", "--frames", "9", "--temporal", "2", "--iterations",
+                        "60", "--channels", str(channels)], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = re.findall(r"\|\s+\[\s*(\d+)\]\s+\|\s+([\d.]+) / ([\d.]+)\s+\|\s+([\d.]+) / ([\d.]+)", r.stdout)
+    assert len(rows) == 9                     # one output per input frame
+    sr = sum(float(x[1]) for x in rows) / len(rows)
+    bc = sum(float(x[3]) for x in rows) / len(rows)
+    assert sr > bc + 1.0, r.stdout            # at least 1 dB over bicubic on this clip
