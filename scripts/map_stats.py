@@ -35,6 +35,19 @@ def stats(name, fl_list):
         # a wave row = 64 consecutive groups (63 owners): fraction of wave rows with any broken group
         nw = (W // 4) // 64 * 64
         any_broken = (~cons[:, :nw]).view(H, -1, 64).any(-1).float().mean().item()
+        # LR pixels whose 5x5 HR neighbourhood is warped by one integer translation
+        idx2 = idx.view(H, W)
+        off = idx2 - (torch.arange(H, device=idx.device).view(H, 1) * W + torch.arange(W, device=idx.device).view(1, W))
+        off = torch.where(inside, off, torch.full_like(off, -(1 << 40)))
+        import torch.nn.functional as F
+        o4 = off.float().view(1, 1, H, W)
+        mx = F.max_pool2d(o4, 5, stride=4, padding=2)      # window centred on (4y, 4x)
+        mn = -F.max_pool2d(-o4, 5, stride=4, padding=2)
+        centre = off[::4, ::4].float()
+        clean = ((mx[0, 0] == mn[0, 0]) & (centre > -1e12))
+        clean_rows = clean.float().mean().item()
+        wave_clean = clean[:, :(W // 4) // 63 * 63].reshape(H // 4, -1, 63).all(-1).float().mean().item()
+        print(f"   pure-translation 5x5 patches: {clean_rows*100:.2f}% of LR pixels; 63-px wave rows entirely clean: {wave_clean*100:.1f}%")
         print(f"{name} frame {k}: consecutive groups {cons.float().mean().item()*100:.2f}%  broken: x-jitter(|dx|<=1,dy=0) "
               f"{xj.float().mean().item()*100:.2f}%  two-run {two.float().mean().item()*100:.2f}%  |d|<=15 "
               f"{small.float().mean().item()*100:.2f}%  wave-rows with a broken group {any_broken*100:.1f}%", flush=True)

@@ -18,9 +18,13 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--lam", type=float, default=0.03)
 ap.add_argument("--shift", type=float, default=1.7, help="camera translation per frame, LR pixels")
+ap.add_argument("--rot", type=float, default=0.002, help="camera rotation scale, radians")
+ap.add_argument("--first", type=int, default=0, help="index of the window's first frame on the camera path")
 a = ap.parse_args()
 
-lr, flows, _ = synth.make_sequence(a.K, a.rows, a.cols, a.ch, a.scale, seed=1234, device="cuda", max_shift=a.shift)
+lr, flows, _ = synth.make_sequence(a.first + a.K, a.rows, a.cols, a.ch, a.scale, seed=1234, device="cuda",
+                                   max_shift=a.shift, max_rot=a.rot)
+lr, flows = lr[a.first:], flows[a.first:]
 y = [f.to(torch.float32) for f in lr]
 sr = api.BTV_L1()
 sr.set("scale", a.scale)

@@ -138,12 +138,12 @@ def true_forward_flow(cam0: Camera, cam1: Camera, lr_rows: int, lr_cols: int, sc
 
 
 def make_sequence(n_frames: int, lr_rows: int, lr_cols: int, channels: int, scale: int, seed: int = 1234,
-                  device="cpu", noise: bool = False, keep_gold: bool = False, max_shift: float = 1.7
-                  ) -> Tuple[List[torch.Tensor], List[torch.Tensor], List[torch.Tensor]]:
+                  device="cpu", noise: bool = False, keep_gold: bool = False, max_shift: float = 1.7,
+                  max_rot: float = 0.002) -> Tuple[List[torch.Tensor], List[torch.Tensor], List[torch.Tensor]]:
     """Returns (lr_frames uint8, true forward flows (n-1), gold HR frames uint8 or []).
 
-    max_shift bounds the camera translation per frame, in LR pixels."""
-    cams = camera_path(n_frames, seed, max_shift=max_shift)
+    max_shift bounds the camera translation per frame (LR pixels), max_rot scales its rotation (radians)."""
+    cams = camera_path(n_frames, seed, max_shift=max_shift, max_rot=max_rot)
     gen = torch.Generator().manual_seed(seed + 1)
     lr, gold = [], []
     for t in range(n_frames):
