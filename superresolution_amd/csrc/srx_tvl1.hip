@@ -247,60 +247,115 @@ __device__ __forceinline__ unsigned long long error_term(float du1, float du2)
     return (unsigned long long)(q * 1073741824.0f);
 }
 
-// Inner iteration, first half: thresholding step, divergence of p, primal update, error.
-// err[it] receives the iteration's fixed-point error (integer adds: order independent).
-// The iteration runs only if the previous one's error exceeded the threshold; err[] starts at zero,
-// so once one iteration has been skipped or has converged all later ones see "converged" too.
-__global__ __launch_bounds__(256) void k_tvl1_u(const float* __restrict__ I1wx, const float* __restrict__ I1wy,
-                                                 const float* __restrict__ grad, const float* __restrict__ rho_c,
-                                                 float* __restrict__ u1, float* __restrict__ u2,
-                                                 const float* __restrict__ p11, const float* __restrict__ p12,
-                                                 const float* __restrict__ p21, const float* __restrict__ p22, int rows,
-                                                 int cols, float l_t, float theta, unsigned long long* __restrict__ err,
-                                                 int it, unsigned long long thr)
+// One inner iteration in one launch: thresholding step, divergence of p, primal update and error,
+// then the forward gradient of the new u and the dual update.
+//
+// The dual update at a pixel needs the new u of its right and lower neighbours, so a block computes
+// the new u for its 32x8 tile plus one column to the right and one row below (those are recomputed,
+// not exchanged) and keeps them in LDS.  Because a neighbouring block recomputes pixels of this tile
+// from the old values, nothing is updated in place: u and p are read from one buffer set and
+// written to the other, and the host swaps the sets every iteration.
+//
+// err[it] receives the iteration's fixed-point error (integer adds: order independent).  The
+// iteration runs only if the previous one's error exceeded the threshold; err[] starts at zero, so
+// once one iteration has been skipped or has converged all later ones see "converged" too (and the
+// result stays in the set the last executed iteration wrote).
+struct Tvl1Planes
+{
+    const float *I1wx, *I1wy, *grad, *rho_c;
+    const float *u1, *u2, *p11, *p12, *p21, *p22; // read
+    float *nu1, *nu2, *np11, *np12, *np21, *np22; // written
+};
+
+constexpr int kItX = 32, kItY = 8;
+
+__device__ __forceinline__ void tvl1_new_u(const Tvl1Planes& P, int x, int y, int cols, float l_t, float theta,
+                                           float& n1, float& n2, float& a, float& b)
+{
+    const size_t i = (size_t)y * cols + x;
+    const float gx = P.I1wx[i], gy = P.I1wy[i], g = P.grad[i];
+    a = P.u1[i], b = P.u2[i];
+    const float rho = P.rho_c[i] + (gx * a + gy * b);
+    float d1 = 0.0f, d2 = 0.0f;
+    if (rho < -l_t * g)
+    {
+        d1 = l_t * gx;
+        d2 = l_t * gy;
+    }
+    else if (rho > l_t * g)
+    {
+        d1 = -l_t * gx;
+        d2 = -l_t * gy;
+    }
+    else if (g > 1.1920929e-07f)
+    {
+        const float fi = -rho / g;
+        d1 = fi * gx;
+        d2 = fi * gy;
+    }
+    const float v1 = a + d1, v2 = b + d2;
+    const float q11 = P.p11[i], q12 = P.p12[i], q21 = P.p21[i], q22 = P.p22[i];
+    const float div1 = (x > 0 ? q11 - P.p11[i - 1] : q11) + (y > 0 ? q12 - P.p12[i - cols] : q12);
+    const float div2 = (x > 0 ? q21 - P.p21[i - 1] : q21) + (y > 0 ? q22 - P.p22[i - cols] : q22);
+    n1 = v1 + theta * div1;
+    n2 = v2 + theta * div2;
+}
+
+__global__ __launch_bounds__(256) void k_tvl1_iter(Tvl1Planes P, int rows, int cols, float l_t, float theta, float taut,
+                                                    unsigned long long* __restrict__ err, int it,
+                                                    unsigned long long thr)
 {
     if (it > 0 && err[it - 1] <= thr)
         return;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    __shared__ float su1[(kItY + 1) * (kItX + 1)], su2[(kItY + 1) * (kItX + 1)];
+    __shared__ unsigned long long part[4];
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * kItX + tx;
+    const int x0 = blockIdx.x * kItX, y0 = blockIdx.y * kItY;
+    const int x = x0 + tx, y = y0 + ty;
+    const bool own = x < cols && y < rows;
     unsigned long long e = 0;
-    if (x < cols && y < rows)
+    float n1 = 0.f, n2 = 0.f;
+    if (own)
+    {
+        float a, b;
+        tvl1_new_u(P, x, y, cols, l_t, theta, n1, n2, a, b);
+        e = error_term(n1 - a, n2 - b);
+        su1[ty * (kItX + 1) + tx] = n1;
+        su2[ty * (kItX + 1) + tx] = n2;
+    }
+    // the column right of the tile (threads 0..7) and the row below it (threads 8..39)
+    if (tid < kItY + kItX)
+    {
+        const int hx = tid < kItY ? x0 + kItX : x0 + (tid - kItY);
+        const int hy = tid < kItY ? y0 + tid : y0 + kItY;
+        if (hx < cols && hy < rows)
+        {
+            float h1, h2, a, b;
+            tvl1_new_u(P, hx, hy, cols, l_t, theta, h1, h2, a, b);
+            su1[(hy - y0) * (kItX + 1) + (hx - x0)] = h1;
+            su2[(hy - y0) * (kItX + 1) + (hx - x0)] = h2;
+        }
+    }
+    __syncthreads();
+    if (own)
     {
         const size_t i = (size_t)y * cols + x;
-        const float gx = I1wx[i], gy = I1wy[i], g = grad[i], a = u1[i], b = u2[i];
-        const float rho = rho_c[i] + (gx * a + gy * b);
-        float d1 = 0.0f, d2 = 0.0f;
-        if (rho < -l_t * g)
-        {
-            d1 = l_t * gx;
-            d2 = l_t * gy;
-        }
-        else if (rho > l_t * g)
-        {
-            d1 = -l_t * gx;
-            d2 = -l_t * gy;
-        }
-        else if (g > 1.1920929e-07f)
-        {
-            const float fi = -rho / g;
-            d1 = fi * gx;
-            d2 = fi * gy;
-        }
-        const float v1 = a + d1, v2 = b + d2;
-        const float q11 = p11[i], q12 = p12[i], q21 = p21[i], q22 = p22[i];
-        const float div1 = (x > 0 ? q11 - p11[i - 1] : q11) + (y > 0 ? q12 - p12[i - cols] : q12);
-        const float div2 = (x > 0 ? q21 - p21[i - 1] : q21) + (y > 0 ? q22 - p22[i - cols] : q22);
-        const float n1 = v1 + theta * div1, n2 = v2 + theta * div2;
-        e = error_term(n1 - a, n2 - b);
-        u1[i] = n1;
-        u2[i] = n2;
+        const int l = ty * (kItX + 1) + tx;
+        const float u1x = x < cols - 1 ? su1[l + 1] - n1 : 0.0f, u1y = y < rows - 1 ? su1[l + kItX + 1] - n1 : 0.0f;
+        const float u2x = x < cols - 1 ? su2[l + 1] - n2 : 0.0f, u2y = y < rows - 1 ? su2[l + kItX + 1] - n2 : 0.0f;
+        const float g1 = sqrtf(u1x * u1x + u1y * u1y), g2 = sqrtf(u2x * u2x + u2y * u2y);
+        const float ng1 = 1.0f + taut * g1, ng2 = 1.0f + taut * g2;
+        P.nu1[i] = n1;
+        P.nu2[i] = n2;
+        P.np11[i] = (P.p11[i] + taut * u1x) / ng1;
+        P.np12[i] = (P.p12[i] + taut * u1y) / ng1;
+        P.np21[i] = (P.p21[i] + taut * u2x) / ng2;
+        P.np22[i] = (P.p22[i] + taut * u2y) / ng2;
     }
     // block reduction of the integer error, one atomic per block
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
         e += __shfl_down(e, o, 64);
-    __shared__ unsigned long long part[4];
-    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
     if ((tid & 63) == 0)
         part[tid >> 6] = e;
     __syncthreads();
@@ -308,29 +363,162 @@ __global__ __launch_bounds__(256) void k_tvl1_u(const float* __restrict__ I1wx, 
         atomicAdd(&err[it], part[0] + part[1] + part[2] + part[3]);
 }
 
-// second half: forward gradient of u, dual update
-__global__ __launch_bounds__(256) void k_tvl1_p(const float* __restrict__ u1, const float* __restrict__ u2,
-                                                 float* __restrict__ p11, float* __restrict__ p12,
-                                                 float* __restrict__ p21, float* __restrict__ p22, int rows, int cols,
-                                                 float taut, const unsigned long long* __restrict__ err, int it,
-                                                 unsigned long long thr)
+// The same iteration with four pixels of a row per thread and 16-byte accesses, for levels whose
+// width is a multiple of 4 (every plane is then 16-byte aligned row by row).  A block covers
+// 128 x 8 pixels.  Values per pixel are computed exactly as in k_tvl1_iter.
+constexpr int kIt4X = 128, kIt4Y = 8, kIt4Pitch = kIt4X + 4;
+
+__device__ __forceinline__ void tvl1_u_values(float gx, float gy, float g, float rc, float a, float b, float q11,
+                                              float q12, float q21, float q22, float left11, float left21, float up12,
+                                              float up22, bool has_left, bool has_up, float l_t, float theta,
+                                              float& n1, float& n2)
+{
+    const float rho = rc + (gx * a + gy * b);
+    float d1 = 0.0f, d2 = 0.0f;
+    if (rho < -l_t * g)
+    {
+        d1 = l_t * gx;
+        d2 = l_t * gy;
+    }
+    else if (rho > l_t * g)
+    {
+        d1 = -l_t * gx;
+        d2 = -l_t * gy;
+    }
+    else if (g > 1.1920929e-07f)
+    {
+        const float fi = -rho / g;
+        d1 = fi * gx;
+        d2 = fi * gy;
+    }
+    const float v1 = a + d1, v2 = b + d2;
+    const float div1 = (has_left ? q11 - left11 : q11) + (has_up ? q12 - up12 : q12);
+    const float div2 = (has_left ? q21 - left21 : q21) + (has_up ? q22 - up22 : q22);
+    n1 = v1 + theta * div1;
+    n2 = v2 + theta * div2;
+}
+
+__global__ __launch_bounds__(256) void k_tvl1_iter4(Tvl1Planes P, int rows, int cols, float l_t, float theta,
+                                                     float taut, unsigned long long* __restrict__ err, int it,
+                                                     unsigned long long thr)
 {
     if (it > 0 && err[it - 1] <= thr)
         return;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= cols || y >= rows)
-        return;
-    const size_t i = (size_t)y * cols + x;
-    const float a = u1[i], b = u2[i];
-    const float u1x = x < cols - 1 ? u1[i + 1] - a : 0.0f, u1y = y < rows - 1 ? u1[i + cols] - a : 0.0f;
-    const float u2x = x < cols - 1 ? u2[i + 1] - b : 0.0f, u2y = y < rows - 1 ? u2[i + cols] - b : 0.0f;
-    const float g1 = sqrtf(u1x * u1x + u1y * u1y), g2 = sqrtf(u2x * u2x + u2y * u2y);
-    const float ng1 = 1.0f + taut * g1, ng2 = 1.0f + taut * g2;
-    p11[i] = (p11[i] + taut * u1x) / ng1;
-    p12[i] = (p12[i] + taut * u1y) / ng1;
-    p21[i] = (p21[i] + taut * u2x) / ng2;
-    p22[i] = (p22[i] + taut * u2y) / ng2;
+    __shared__ __attribute__((aligned(16))) float su1[(kIt4Y + 1) * kIt4Pitch], su2[(kIt4Y + 1) * kIt4Pitch];
+    __shared__ unsigned long long part[4];
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 32 + tx;
+    const int x0 = blockIdx.x * kIt4X, y0 = blockIdx.y * kIt4Y;
+
+    // new u of four pixels starting at (x, y); returns false outside the image
+    auto new_u4 = [&](int x, int y, float (&n1)[4], float (&n2)[4], float (&a)[4], float (&b)[4], float4 (&q)[4]) {
+        if (x >= cols || y >= rows)
+            return false;
+        const size_t i = (size_t)y * cols + x;
+        const float4 gx = *(const float4*)(P.I1wx + i), gy = *(const float4*)(P.I1wy + i);
+        const float4 g = *(const float4*)(P.grad + i), rc = *(const float4*)(P.rho_c + i);
+        const float4 u1 = *(const float4*)(P.u1 + i), u2 = *(const float4*)(P.u2 + i);
+        q[0] = *(const float4*)(P.p11 + i), q[1] = *(const float4*)(P.p12 + i);
+        q[2] = *(const float4*)(P.p21 + i), q[3] = *(const float4*)(P.p22 + i);
+        float4 up12 = make_float4(0.f, 0.f, 0.f, 0.f), up22 = up12;
+        if (y > 0)
+        {
+            up12 = *(const float4*)(P.p12 + i - cols);
+            up22 = *(const float4*)(P.p22 + i - cols);
+        }
+        float l11 = 0.f, l21 = 0.f;
+        if (x > 0)
+        {
+            l11 = P.p11[i - 1];
+            l21 = P.p21[i - 1];
+        }
+        const float gxv[4] = {gx.x, gx.y, gx.z, gx.w}, gyv[4] = {gy.x, gy.y, gy.z, gy.w};
+        const float gv[4] = {g.x, g.y, g.z, g.w}, rcv[4] = {rc.x, rc.y, rc.z, rc.w};
+        const float q11[4] = {q[0].x, q[0].y, q[0].z, q[0].w}, q12[4] = {q[1].x, q[1].y, q[1].z, q[1].w};
+        const float q21[4] = {q[2].x, q[2].y, q[2].z, q[2].w}, q22[4] = {q[3].x, q[3].y, q[3].z, q[3].w};
+        const float u12[4] = {up12.x, up12.y, up12.z, up12.w}, u22[4] = {up22.x, up22.y, up22.z, up22.w};
+        a[0] = u1.x, a[1] = u1.y, a[2] = u1.z, a[3] = u1.w;
+        b[0] = u2.x, b[1] = u2.y, b[2] = u2.z, b[3] = u2.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            tvl1_u_values(gxv[e], gyv[e], gv[e], rcv[e], a[e], b[e], q11[e], q12[e], q21[e], q22[e],
+                          e == 0 ? l11 : q11[e - 1], e == 0 ? l21 : q21[e - 1], u12[e], u22[e], x + e > 0, y > 0, l_t,
+                          theta, n1[e], n2[e]);
+        return true;
+    };
+
+    const int x = x0 + 4 * tx, y = y0 + ty;
+    float n1[4], n2[4], a[4], b[4];
+    float4 q[4];
+    unsigned long long e = 0;
+    const bool own = new_u4(x, y, n1, n2, a, b, q);
+    if (own)
+    {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            e += error_term(n1[k] - a[k], n2[k] - b[k]);
+        *(float4*)&su1[ty * kIt4Pitch + 4 * tx] = make_float4(n1[0], n1[1], n1[2], n1[3]);
+        *(float4*)&su2[ty * kIt4Pitch + 4 * tx] = make_float4(n2[0], n2[1], n2[2], n2[3]);
+    }
+    // the row below the tile (threads 0..31, four pixels each) and the column right of it (threads 32..39)
+    if (tid < 32)
+    {
+        float h1[4], h2[4], ha[4], hb[4];
+        float4 hq[4];
+        if (new_u4(x0 + 4 * tid, y0 + kIt4Y, h1, h2, ha, hb, hq))
+        {
+            *(float4*)&su1[kIt4Y * kIt4Pitch + 4 * tid] = make_float4(h1[0], h1[1], h1[2], h1[3]);
+            *(float4*)&su2[kIt4Y * kIt4Pitch + 4 * tid] = make_float4(h2[0], h2[1], h2[2], h2[3]);
+        }
+    }
+    else if (tid < 32 + kIt4Y)
+    {
+        const int hx = x0 + kIt4X, hy = y0 + (tid - 32);
+        if (hx < cols && hy < rows)
+        {
+            Tvl1Planes Q = P;
+            float h1, h2, ha, hb;
+            tvl1_new_u(Q, hx, hy, cols, l_t, theta, h1, h2, ha, hb);
+            su1[(tid - 32) * kIt4Pitch + kIt4X] = h1;
+            su2[(tid - 32) * kIt4Pitch + kIt4X] = h2;
+        }
+    }
+    __syncthreads();
+    if (own)
+    {
+        const size_t i = (size_t)y * cols + x;
+        const int l = ty * kIt4Pitch + 4 * tx;
+        float o11[4], o12[4], o21[4], o22[4];
+        const float q11[4] = {q[0].x, q[0].y, q[0].z, q[0].w}, q12[4] = {q[1].x, q[1].y, q[1].z, q[1].w};
+        const float q21[4] = {q[2].x, q[2].y, q[2].z, q[2].w}, q22[4] = {q[3].x, q[3].y, q[3].z, q[3].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            const bool has_r = x + k < cols - 1, has_d = y < rows - 1;
+            const float r1 = k < 3 ? n1[k + 1] : su1[l + 4], r2 = k < 3 ? n2[k + 1] : su2[l + 4];
+            const float u1x = has_r ? r1 - n1[k] : 0.0f, u1y = has_d ? su1[l + kIt4Pitch + k] - n1[k] : 0.0f;
+            const float u2x = has_r ? r2 - n2[k] : 0.0f, u2y = has_d ? su2[l + kIt4Pitch + k] - n2[k] : 0.0f;
+            const float g1 = sqrtf(u1x * u1x + u1y * u1y), g2 = sqrtf(u2x * u2x + u2y * u2y);
+            const float ng1 = 1.0f + taut * g1, ng2 = 1.0f + taut * g2;
+            o11[k] = (q11[k] + taut * u1x) / ng1;
+            o12[k] = (q12[k] + taut * u1y) / ng1;
+            o21[k] = (q21[k] + taut * u2x) / ng2;
+            o22[k] = (q22[k] + taut * u2y) / ng2;
+        }
+        *(float4*)(P.nu1 + i) = make_float4(n1[0], n1[1], n1[2], n1[3]);
+        *(float4*)(P.nu2 + i) = make_float4(n2[0], n2[1], n2[2], n2[3]);
+        *(float4*)(P.np11 + i) = make_float4(o11[0], o11[1], o11[2], o11[3]);
+        *(float4*)(P.np12 + i) = make_float4(o12[0], o12[1], o12[2], o12[3]);
+        *(float4*)(P.np21 + i) = make_float4(o21[0], o21[1], o21[2], o21[3]);
+        *(float4*)(P.np22 + i) = make_float4(o22[0], o22[1], o22[2], o22[3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        e += __shfl_down(e, o, 64);
+    if ((tid & 63) == 0)
+        part[tid >> 6] = e;
+    __syncthreads();
+    if (tid == 0)
+        atomicAdd(&err[it], part[0] + part[1] + part[2] + part[3]);
 }
 
 // cv::resize(INTER_LINEAR) of the two flow planes to the next finer level, times 2
@@ -408,6 +596,7 @@ struct Tvl1::Impl
     };
     Level lv[kMaxScales];
     DeviceBuffer I1x, I1y, I1wx, I1wy, grad, rho_c, p, err, raw0, raw1;
+    DeviceBuffer u_alt, p_alt; // second set of u (2 planes) and p (4 planes) for the ping-pong of k_tvl1_iter
     PinnedBuffer host_err;
 };
 
@@ -505,6 +694,10 @@ int Tvl1::calc_gray(const float* I0, const float* I1, int rows, int cols, const 
             return rc;
     if (int rc = m.p.reserve(4 * px0 * sizeof(float)))
         return rc;
+    if (int rc = m.p_alt.reserve(4 * px0 * sizeof(float)))
+        return rc;
+    if (int rc = m.u_alt.reserve(2 * px0 * sizeof(float)))
+        return rc;
     const int iters = std::max(p.iterations, 1);
     if (int rc = m.err.reserve((size_t)iters * sizeof(unsigned long long)))
         return rc;
@@ -526,7 +719,6 @@ int Tvl1::calc_gray(const float* I0, const float* I1, int rows, int cols, const 
         const size_t n = (size_t)R * C;
         const dim3 g2 = grid2(C, R, b2);
         float* p11 = m.p.as<float>();
-        float *p12 = p11 + n, *p21 = p11 + 2 * n, *p22 = p11 + 3 * n;
         hipLaunchKernelGGL(k_centered_gradient, g2, b2, 0, st, L.I1.as<float>(), R, C, m.I1x.as<float>(),
                            m.I1y.as<float>());
         SRX_LAUNCH_CHECK("centered_gradient");
@@ -541,16 +733,29 @@ int Tvl1::calc_gray(const float* I0, const float* I1, int rows, int cols, const 
             SRX_LAUNCH_CHECK("warp");
             SRX_HIP(hipMemsetAsync(m.err.get(), 0, (size_t)iters * sizeof(unsigned long long), st));
             int done = iters; // iterations that ran
+            float* ua[2][2] = {{L.u1.as<float>(), L.u2.as<float>()}, {m.u_alt.as<float>(), m.u_alt.as<float>() + n}};
+            float* pa[2] = {p11, m.p_alt.as<float>()};
+            const dim3 bi(kItX, kItY);
+            const dim3 gi = grid2(C, R, bi);
             for (int it0 = 0; it0 < iters; it0 += kPollStride)
             {
                 const int it1 = std::min(it0 + kPollStride, iters);
                 for (int it = it0; it < it1; ++it)
                 {
-                    hipLaunchKernelGGL(k_tvl1_u, g2, b2, 0, st, m.I1wx.as<float>(), m.I1wy.as<float>(),
-                                       m.grad.as<float>(), m.rho_c.as<float>(), L.u1.as<float>(), L.u2.as<float>(),
-                                       p11, p12, p21, p22, R, C, l_t, theta, m.err.as<unsigned long long>(), it, thr);
-                    hipLaunchKernelGGL(k_tvl1_p, g2, b2, 0, st, L.u1.as<float>(), L.u2.as<float>(), p11, p12, p21,
-                                       p22, R, C, taut, m.err.as<unsigned long long>(), it, thr);
+                    const int src = it & 1, dst = src ^ 1;
+                    Tvl1Planes P;
+                    P.I1wx = m.I1wx.as<float>(), P.I1wy = m.I1wy.as<float>(), P.grad = m.grad.as<float>();
+                    P.rho_c = m.rho_c.as<float>();
+                    P.u1 = ua[src][0], P.u2 = ua[src][1];
+                    P.p11 = pa[src], P.p12 = pa[src] + n, P.p21 = pa[src] + 2 * n, P.p22 = pa[src] + 3 * n;
+                    P.nu1 = ua[dst][0], P.nu2 = ua[dst][1];
+                    P.np11 = pa[dst], P.np12 = pa[dst] + n, P.np21 = pa[dst] + 2 * n, P.np22 = pa[dst] + 3 * n;
+                    if (C % 4 == 0)
+                        hipLaunchKernelGGL(k_tvl1_iter4, grid2(C, R, dim3(kIt4X, kIt4Y)), dim3(32, kIt4Y), 0, st, P, R,
+                                           C, l_t, theta, taut, m.err.as<unsigned long long>(), it, thr);
+                    else
+                        hipLaunchKernelGGL(k_tvl1_iter, gi, bi, 0, st, P, R, C, l_t, theta, taut,
+                                           m.err.as<unsigned long long>(), it, thr);
                 }
                 SRX_LAUNCH_CHECK("tvl1 iteration");
                 // the queued kernels already stop by themselves on the device; looking at the error here only
@@ -567,6 +772,13 @@ int Tvl1::calc_gray(const float* I0, const float* I1, int rows, int cols, const 
                     }
                 if (stop)
                     break;
+            }
+            if (done & 1)
+            {
+                // an odd number of iterations leaves the result in the second buffer set
+                SRX_HIP(hipMemcpyAsync(ua[0][0], ua[1][0], n * sizeof(float), hipMemcpyDeviceToDevice, st));
+                SRX_HIP(hipMemcpyAsync(ua[0][1], ua[1][1], n * sizeof(float), hipMemcpyDeviceToDevice, st));
+                SRX_HIP(hipMemcpyAsync(pa[0], pa[1], 4 * n * sizeof(float), hipMemcpyDeviceToDevice, st));
             }
             executed += done;
         }
