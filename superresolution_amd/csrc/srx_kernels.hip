@@ -33,6 +33,7 @@
 // blur size, BTV size) and specialised ones (scale 4, 5-tap blur, BTV 7).
 #include "srx_common.h"
 
+
 #include <cstring>
 
 namespace srx
@@ -65,6 +66,26 @@ constexpr int kFwdLutSize = 26;
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+// Loads and stores of data that is touched once per launch (maps, signs on their way out): marked
+// non-temporal so that they do not push the lines of X, which every window frame gathers again, out of L2.
+__device__ __forceinline__ uint2 stream_load(const uint2* p)
+{
+    const v2u v = __builtin_nontemporal_load((const v2u*)p);
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ uint4 stream_load(const uint4* p)
+{
+    const v4u v = __builtin_nontemporal_load((const v4u*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void stream_store(uint32_t* p, uint32_t v)
+{
+    __builtin_nontemporal_store(v, p);
+}
+
 // volatile LDS vector access keeps 16-byte ds_read_b128 from being split into narrower reads
 typedef __attribute__((address_space(3))) const volatile v4i lds_cv4i;
 
@@ -642,7 +663,7 @@ __global__ __launch_bounds__(256, SRX_A_WAVES) void k_forward_sign_s4(const floa
     uint32_t* sp = (uint32_t*)signs.p[k] + 2 * (size_t)xl;
     const float k0 = g.k[2], k1 = g.k[3], k2 = g.k[4];
 
-    auto load_group = [&](int Y) { return grp[(size_t)reflect101(Y, H) * w]; };
+    auto load_group = [&](int Y) { return stream_load(grp + (size_t)reflect101(Y, H) * w); };
     auto consecutive = [](const uint2& gm) { return (gm.x & kGrpRun) != 0; };
     auto gather = [&](const uint2& gm, float4 (&a)[CH]) {
 #pragma unroll
@@ -769,9 +790,9 @@ __global__ __launch_bounds__(256, SRX_A_WAVES) void k_forward_sign_s4(const floa
         }
         if (owner)
         {
-            sp[2 * (size_t)y * w] = sg;
+            stream_store(sp + 2 * (size_t)y * w, sg);
             if (y > 0)
-                sp[2 * (size_t)(y - 1) * w + 1] = sg;
+                stream_store(sp + 2 * (size_t)(y - 1) * w + 1, sg);
         }
 #pragma unroll
         for (int c = 0; c < CH; ++c)
@@ -836,7 +857,10 @@ __device__ __forceinline__ int sign_of_difference(float t)
 //    ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) reads 16
 //    consecutive 16-byte chunks of one LDS row: conflict-free at any row pitch.
 #ifndef SRX_B_WAVES
-#define SRX_B_WAVES 5
+#define SRX_B_WAVES 6
+#endif
+#ifndef SRX_B_PARK
+#define SRX_B_PARK 1
 #endif
 template <int CH>
 __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
@@ -852,7 +876,10 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
     constexpr int NV = 3;               // vectors per window row: columns [4tx, 4tx+12) of the LDS row
     __shared__ __attribute__((aligned(16))) float tile[CH * LROWS * PITCH];
     __shared__ uint4 lut[2 * kFwdLutSize]; // [li] = weights, [kFwdLutSize + li].x = their sum
-    __shared__ float park[CH * PXT * 256];  // regulariser values rest here while the frame loop runs
+    // regulariser values rest while the frame loop runs: the first kPark channels in LDS, the others in registers
+    constexpr int kPark = SRX_B_PARK < CH ? SRX_B_PARK : CH;
+    __shared__ float park[(kPark > 0 ? kPark : 1) * PXT * 256];
+    float keep[CH][PXT];
 
     const unsigned t = xcd_contiguous(blockIdx.x, n_tiles);
     if (t >= n_tiles)
@@ -875,7 +902,7 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
     // first frame's map entries: issued before the tile is staged
     uint4 cur = make_uint4(0, 0, 0, 0);
     if (K > 0)
-        cur = *(const uint4*)((const uint32_t*)dec_fwd.p[0] + pix);
+        cur = stream_load((const uint4*)((const uint32_t*)dec_fwd.p[0] + pix));
 
     if (tid < kFwdLutSize)
     {
@@ -993,7 +1020,12 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
             }
 #pragma unroll
             for (int e = 0; e < PXT; ++e)
-                park[(c * PXT + e) * 256 + tid] = reg[e];
+            {
+                if (c < kPark)
+                    park[(c * PXT + e) * 256 + tid] = reg[e];
+                else
+                    keep[c][e] = reg[e];
+            }
         }
     }
 
@@ -1019,7 +1051,7 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
         {
             uint4 nxt = cur;
             if (k + 1 < K)
-                nxt = *(const uint4*)((const uint32_t*)dec_fwd.p[k + 1] + pix);
+                nxt = stream_load((const uint4*)((const uint32_t*)dec_fwd.p[k + 1] + pix));
             const char* sg = (const char*)signs.p[k];
             const uint32_t ev[PXT] = {cur.x, cur.y, cur.z, cur.w};
             uint4_a8 qs[PXT];
@@ -1073,7 +1105,8 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
             float d = (float)(acc[p][c] - bias[p]) * 0.00390625f;
             if (lambda > 0)
             {
-                const float rg = interior ? park[(c * PXT + p) * 256 + tid] : 0.0f;
+                const float rv = c < kPark ? park[(c * PXT + p) * 256 + tid] : keep[c][p];
+                const float rg = interior ? rv : 0.0f;
                 d = (float)((double)d + (double)rg * (-lambda));
             }
             outv[p] = (float)((double)__int_as_float(ctr[p]) + (double)d * tau);
