@@ -839,12 +839,14 @@ __device__ __forceinline__ int sign_of_difference(float t)
 // Back-projection of all K frames + BTV regulariser + update for one 64x16 tile
 // of HR pixels per block; each thread owns 4 consecutive pixels of one row.
 // X and X_out are planar.
-//  * BTV: the tile of X (+3 px halo) sits in LDS, one plane per channel;
+//  * BTV, one channel after the other: the channel's tile of X (+3 px halo) is
+//    staged in LDS (the next channel's loads are in flight meanwhile);
 //    sign(a-b) is a float subtract (two at a time where the window registers
 //    pair up) and an integer clamp; accumulation order is the reference's
-//    (lib/src/btv_l1.cpp:221-233).  Channels are processed one after the other,
-//    which keeps the register windows small; the results rest in LDS while the
-//    frame loop runs.  NaN - x counts as +1 instead of comparing unordered.
+//    (lib/src/btv_l1.cpp:221-233).  A small tile and few live registers keep 7
+//    waves per SIMD resident, which is what hides the gather latency of the
+//    frame loop.  The results rest in LDS / registers while that loop runs.
+//    NaN - x counts as +1 instead of comparing unordered.
 //  * per frame: one 16-byte load of 4 decoded forward-map entries (fetched one
 //    frame ahead), then per pixel one 16-byte read of the 2x2 block of sign
 //    cells from the pair plane, times the entry's integer weights.  A sign word
@@ -857,11 +859,12 @@ __device__ __forceinline__ int sign_of_difference(float t)
 //    ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) reads 16
 //    consecutive 16-byte chunks of one LDS row: conflict-free at any row pitch.
 #ifndef SRX_B_WAVES
-#define SRX_B_WAVES 6
+#define SRX_B_WAVES 7
 #endif
 #ifndef SRX_B_PARK
-#define SRX_B_PARK 1
+#define SRX_B_PARK 2
 #endif
+
 template <int CH>
 __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
     const float* __restrict__ X, float* __restrict__ X_out, int H, int W, size_t ps, PtrList dec_fwd,
@@ -874,7 +877,7 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
     constexpr int LROWS = TYN + 2 * HALO;
     constexpr int RV = PITCH / 4;       // 16-byte vectors per LDS row
     constexpr int NV = 3;               // vectors per window row: columns [4tx, 4tx+12) of the LDS row
-    __shared__ __attribute__((aligned(16))) float tile[CH * LROWS * PITCH];
+    __shared__ __attribute__((aligned(16))) float tile[LROWS * PITCH]; // one channel at a time
     __shared__ uint4 lut[2 * kFwdLutSize]; // [li] = weights, [kFwdLutSize + li].x = their sum
     // regulariser values rest while the frame loop runs: the first kPark channels in LDS, the others in registers
     constexpr int kPark = SRX_B_PARK < CH ? SRX_B_PARK : CH;
@@ -909,49 +912,48 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
         lut[tid] = make_uint4(fw.w[tid][0], fw.w[tid][1], fw.w[tid][2], fw.w[tid][3]);
         lut[kFwdLutSize + tid] = make_uint4(fw.wsum[tid], 0, 0, 0);
     }
-    // ---- stage the X tile (as keys) in LDS; all loads are issued before the first is consumed
-    {
-        constexpr int NCH = CH * LROWS * RV; // 16-byte chunks
-        constexpr int NIT = (NCH + 255) / 256;
-        float4 stage[NIT];
+    // ---- BTV regulariser, one channel at a time: the channel's tile of X (+3 px halo) is staged in LDS
+    // (branch-free clamped loads, the next channel's issued before this channel's arithmetic starts)
+    constexpr int NCH1 = LROWS * RV; // 16-byte chunks of one channel's tile
+    constexpr int NIT1 = (NCH1 + 255) / 256;
+    float4 stage[NIT1];
+    auto load_stage = [&](int c) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it)
+        for (int it = 0; it < NIT1; ++it)
         {
-            // branch-free: chunks outside the image read a clamped address (and are zeroed below)
-            const int idx = min(tid + it * 256, NCH - 1);
-            const int c = idx / (LROWS * RV), rem = idx - c * (LROWS * RV);
-            const int r = rem / RV, c4 = rem - r * RV;
+            const int idx = min(tid + it * 256, NCH1 - 1);
+            const int r = idx / RV, c4 = idx - r * RV;
             const int gi = min(max(i0 - HALO + r, 0), H - 1), gj = min(max(j0 - HL + 4 * c4, 0), W - 4);
             stage[it] = *(const float4*)(X + c * ps + (size_t)gi * W + gj);
         }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it)
-        {
-            const int idx = tid + it * 256;
-            const int c = idx / (LROWS * RV), rem = idx - c * (LROWS * RV);
-            const int r = rem / RV, c4 = rem - r * RV;
-            const int gi = i0 - HALO + r, gj = j0 - HL + 4 * c4;
-            // W and gj are multiples of 4: a chunk is entirely inside or outside the row
-            const bool in = gi >= 0 && gi < H && gj >= 0 && gj < W;
-            if (idx < NCH)
-            {
-                const float4 v = stage[it];
-                // outside the image the tile holds 0; those cells are never read by an interior pixel
-                *(float4*)&tile[4 * idx] = in ? make_float4(fold_zero(v.x), fold_zero(v.y), fold_zero(v.z), fold_zero(v.w))
-                                              : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- BTV regulariser from the LDS tile, one channel at a time
+    };
     const int lrow = ty + HALO;
     if (lambda > 0)
     {
+        load_stage(0);
 #pragma unroll
         for (int c = 0; c < CH; ++c)
         {
-            lds_cv4i* tp = (lds_cv4i*)tile + (c * LROWS + lrow) * RV + tx; // window start of the centre row
+#pragma unroll
+            for (int it = 0; it < NIT1; ++it)
+            {
+                const int idx = tid + it * 256;
+                const int r = idx / RV, c4 = idx - r * RV;
+                const int gi = i0 - HALO + r, gj = j0 - HL + 4 * c4;
+                // W and gj are multiples of 4: a chunk is entirely inside or outside the row
+                const bool in = gi >= 0 && gi < H && gj >= 0 && gj < W;
+                if (idx < NCH1)
+                {
+                    const float4 v = stage[it];
+                    // outside the image the tile holds 0; those cells are never read by an interior pixel
+                    *(float4*)&tile[4 * idx] = in ? make_float4(fold_zero(v.x), fold_zero(v.y), fold_zero(v.z), fold_zero(v.w))
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            __syncthreads();
+            if (c + 1 < CH)
+                load_stage(c + 1);
+            lds_cv4i* tp = (lds_cv4i*)tile + lrow * RV + tx; // window start of the centre row
             v4i cv[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v)
@@ -1026,9 +1028,11 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
                 else
                     keep[c][e] = reg[e];
             }
+            __syncthreads(); // the tile is rewritten for the next channel
         }
     }
-
+    else
+        __syncthreads(); // the weight table
     // ---- sum over frames of M^T H^T D^T sign, in units of 1/256
     int acc[PXT][CH];
     int bias[PXT];
@@ -1095,8 +1099,9 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
 #pragma unroll
     for (int c = 0; c < CH; ++c)
     {
-        // the centre pixels come back from the tile, the regulariser from its parking slot
-        const v4i ctr = ((lds_cv4i*)tile)[(c * LROWS + lrow) * RV + tx + HL / 4];
+        // the centre pixels are read again (they are in L2), the regulariser comes from its parking slot
+        const float4 ctr = *(const float4*)(X + c * ps + pix);
+        const float cxv[PXT] = {ctr.x, ctr.y, ctr.z, ctr.w};
         float outv[PXT];
 #pragma unroll
         for (int p = 0; p < PXT; ++p)
@@ -1109,7 +1114,7 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
                 const float rg = interior ? rv : 0.0f;
                 d = (float)((double)d + (double)rg * (-lambda));
             }
-            outv[p] = (float)((double)__int_as_float(ctr[p]) + (double)d * tau);
+            outv[p] = (float)((double)cxv[p] + (double)d * tau);
         }
         *(float4*)(X_out + c * ps + pix) = make_float4(outv[0], outv[1], outv[2], outv[3]);
     }
