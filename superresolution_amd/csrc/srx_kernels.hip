@@ -19,7 +19,13 @@
 //                   backward: linear source pixel index, or rows*cols (the
 //                             zero pixel) when the source is outside; behind
 //                             the rows*cols entries follows the group map, two
-//                             words per 4 pixels of a row (kGrp* below);
+//                             words per 4 pixels of a row (kGrp* below), laid
+//                             out per LR pixel (y, x): first all "word 0", four
+//                             per LR pixel, for HR rows 4y-1 .. 4y+2 (reflected
+//                             at the top) and columns 4x .. 4x+3, then all
+//                             "word 1" in the same order - the forward kernel
+//                             reads an LR pixel's four rows with two 16-byte
+//                             loads;
 //                   forward:  see kFwd* below.
 //   signs         one uint32 word per LR pixel and window frame: sign+1 (0,1,2)
 //                 of channel c in bits 10c..10c+1.  Generic kernels keep a
@@ -236,13 +242,19 @@ __global__ void k_decode_maps(const short2* __restrict__ fwd_map, const short2* 
         dec_fwd[o] = decode_fwd(fwd_map[o].x, fwd_map[o].y, R, C);
 }
 
-// group map behind the decoded backward map (layout at the top of this file)
-__global__ void k_group_maps(uint32_t* __restrict__ dec_bwd, size_t groups, int W)
+// group map behind the decoded backward map (layout at the top of this file); one thread per entry
+__global__ void k_group_maps(uint32_t* __restrict__ dec_bwd, int H, int W)
 {
-    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= groups)
+    const int w = W >> 2, h = H >> 2;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t entries = (size_t)h * w * 4;
+    if (e >= entries)
         return;
-    const uint4 m = ((const uint4*)dec_bwd)[g];
+    const int r = (int)(e & 3);
+    const size_t cell = e >> 2;
+    const int x = (int)(cell % w), y = (int)(cell / w);
+    const int Y = reflect101(4 * y - 1 + r, H);
+    const uint4 m = *(const uint4*)(dec_bwd + (size_t)Y * W + 4 * x);
     const uint32_t mi[3] = {m.y, m.z, m.w};
     uint32_t w0 = m.x, w1 = 0;
     bool run = true, far = false;
@@ -261,7 +273,9 @@ __global__ void k_group_maps(uint32_t* __restrict__ dec_bwd, size_t groups, int 
         w0 |= kGrpRun;
     else if (far)
         w0 |= kGrpFar;
-    ((uint2*)(dec_bwd + 4 * groups))[g] = make_uint2(w0, w1);
+    uint32_t* grp = dec_bwd + (size_t)H * W;
+    grp[e] = w0;
+    grp[entries + e] = w1;
 }
 
 // ps == 0: interleaved destination; otherwise planar with plane stride ps
@@ -658,12 +672,19 @@ __global__ __launch_bounds__(256, SRX_A_WAVES) void k_forward_sign_s4(const floa
     const bool first = x == 0;
 
     const uint32_t* map = (const uint32_t*)dec_bwd.p[k] + 4 * xl;      // full entries (lanes with a break only)
-    const uint2* grp = (const uint2*)((const uint32_t*)dec_bwd.p[k] + (size_t)H * W) + xl; // group map
+    // group map: word 0 and word 1 of this LR column's four rows, 16 bytes each per LR row
+    const uint4* grp0 = (const uint4*)((const uint32_t*)dec_bwd.p[k] + (size_t)H * W) + xl;
+    const uint4* grp1 = grp0 + (size_t)h * w;
     const float* yk = (const float*)ys.p[k] + (size_t)xl * CH;
     uint32_t* sp = (uint32_t*)signs.p[k] + 2 * (size_t)xl;
     const float k0 = g.k[2], k1 = g.k[3], k2 = g.k[4];
 
-    auto load_group = [&](int Y) { return stream_load(grp + (size_t)reflect101(Y, H) * w); };
+    // entries of HR rows 4y-1 .. 4y+2
+    auto load_groups = [&](int y, uint2 (&m)[4]) {
+        const uint4 a0 = stream_load(grp0 + (size_t)y * w), a1 = stream_load(grp1 + (size_t)y * w);
+        m[0] = make_uint2(a0.x, a1.x), m[1] = make_uint2(a0.y, a1.y);
+        m[2] = make_uint2(a0.z, a1.z), m[3] = make_uint2(a0.w, a1.w);
+    };
     auto consecutive = [](const uint2& gm) { return (gm.x & kGrpRun) != 0; };
     auto gather = [&](const uint2& gm, float4 (&a)[CH]) {
 #pragma unroll
@@ -724,10 +745,10 @@ __global__ __launch_bounds__(256, SRX_A_WAVES) void k_forward_sign_s4(const floa
     float rr[5][CH];
     uint2 mc[4];
     {
-        const uint2 m0 = load_group(4 * y0 - 2);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            mc[r] = load_group(4 * y0 - 1 + r);
+        // HR row 4*y0 - 2 is the last of the LR row above (for y0 = 0 it reflects to row 2, the last of LR row 0)
+        const int ya = max(y0 - 1, 0);
+        const uint2 m0 = make_uint2(((const uint32_t*)(grp0 + (size_t)ya * w))[3], ((const uint32_t*)(grp1 + (size_t)ya * w))[3]);
+        load_groups(y0, mc);
         float4 a[CH];
         float t[CH][3] = {};
         gather(m0, a);
@@ -743,11 +764,7 @@ __global__ __launch_bounds__(256, SRX_A_WAVES) void k_forward_sign_s4(const floa
         for (int r = 0; r < 4; ++r)
             mn[r] = mc[r];
         if (y + 1 < y1)
-        {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                mn[r] = load_group(4 * y + 3 + r);
-        }
+            load_groups(y + 1, mn);
         float yv[CH];
         {
             const packed_floats<CH> v = *(const packed_floats<CH>*)(yk + (size_t)y * w * CH);
@@ -1213,8 +1230,9 @@ int launch_relative_motions(const PtrList& fwd, const MutPtrList& rel, int n, in
 static int launch_group_maps(uint32_t* dec_bwd, size_t hr_px, int hr_cols, hipStream_t st)
 {
     const int bs = 256;
-    const size_t groups = hr_px / 4; // scale 4: every row is a whole number of groups
-    hipLaunchKernelGGL(k_group_maps, dim3((unsigned)((groups + bs - 1) / bs)), dim3(bs), 0, st, dec_bwd, groups, hr_cols);
+    const size_t entries = hr_px / 4; // scale 4: every row is a whole number of groups
+    hipLaunchKernelGGL(k_group_maps, dim3((unsigned)((entries + bs - 1) / bs)), dim3(bs), 0, st, dec_bwd,
+                       (int)(hr_px / hr_cols), hr_cols);
     return check_launch("group_maps");
 }
 
