@@ -646,16 +646,19 @@ template <int N> struct __attribute__((packed, aligned(4))) packed_floats
 #ifndef SRX_A_WAVES
 #define SRX_A_WAVES 3
 #endif
+#ifndef SRX_A_WPB
+#define SRX_A_WPB 1 // waves (work items) per block: single-wave blocks pack the SIMDs best
+#endif
 constexpr int kFwdRowsPerWave = SRX_A_ROWS;
 constexpr int kFwdStrip = 63;
 
 template <int CH>
-__global__ __launch_bounds__(256, SRX_A_WAVES) void k_forward_sign_s4(const float* __restrict__ X, int H, int W,
+__global__ __launch_bounds__(64 * SRX_A_WPB, SRX_A_WAVES) void k_forward_sign_s4(const float* __restrict__ X, int H, int W,
                                                                        size_t ps, PtrList dec_bwd, PtrList ys,
                                                                        MutPtrList signs, int K, GaussK g, int strips_x,
                                                                        unsigned n_items, unsigned n_blocks)
 {
-    const unsigned item = xcd_contiguous(blockIdx.x, n_blocks) * 4 + (threadIdx.x >> 6);
+    const unsigned item = xcd_contiguous(blockIdx.x, n_blocks) * SRX_A_WPB + (threadIdx.x >> 6);
     if (item >= n_items)
         return;
     const int k = item % K;
@@ -1349,8 +1352,8 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
         const int strips_x = (w + kFwdStrip - 1) / kFwdStrip;
         const int row_groups = (h + kFwdRowsPerWave - 1) / kFwdRowsPerWave;
         const unsigned n_items = (unsigned)strips_x * row_groups * K; // one wave each
-        const unsigned n_blocks = (n_items + 3) / 4;
-        const dim3 gr(xcd_grid(n_blocks)), b(256);
+        const unsigned n_blocks = (n_items + SRX_A_WPB - 1) / SRX_A_WPB;
+        const dim3 gr(xcd_grid(n_blocks)), b(64 * SRX_A_WPB);
         if (ch == 1)
             hipLaunchKernelGGL(k_forward_sign_s4<1>, gr, b, 0, st, X, hr_rows, hr_cols, ps, *dec_bwd, y, signs, K, g,
                                strips_x, n_items, n_blocks);
