@@ -1,0 +1,129 @@
+"""Parity at the sizes of the benchmark configurations, where the CPU oracle is too slow for a full solve.
+
+ * cfg1 size (320x240 grey -> 1280x960): a short solve against the oracle itself, bit-exact.
+ * cfg2 / cfg4 sizes (480x270 and 960x540 RGB, window 9): the specialised kernels against the generic
+   kernels, bit-exact - two independent GPU implementations, the generic one pinned to the oracle by
+   the small-size tests.
+ * cfg4 size: the fixed point (lambda = 0, one frame, zero motion, y = D H X evaluated by the same
+   operations) stays fixed, and a solve with lambda = 0 and zero motion is the same for every window
+   frame order (the sum over frames is an integer sum).
+ * cfg3 size (1920x1080 grey pair): TV-L1 of identical frames is exactly zero, and a known sub-pixel
+   translation is recovered to a tenth of a pixel.
+"""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _sequence(K, rows, cols, ch, seed):
+    import torch
+    from superresolution_amd import synth
+
+    lr, flows, _ = synth.make_sequence(K, rows, cols, ch, 4, seed=seed, device="cuda")
+    return [f.to(torch.float32) for f in lr], flows
+
+
+def _solve(y, flows, base, path, **params):
+    from superresolution_amd import api, ops
+
+    ops.set_kernel_path(path)
+    try:
+        sr = api.BTV_L1()
+        for k, v in params.items():
+            sr.set(k, v)
+        return ops.process_device(sr, y, flows, base, return_full=True)
+    finally:
+        ops.set_kernel_path(0)
+
+
+def test_cfg1_size_against_the_oracle():
+    K, rows, cols = 5, 240, 320
+    y, flows = _sequence(K, rows, cols, 1, seed=11)
+    p = oracle.BtvParams(iterations=4)
+    ref_out, ref_full = oracle.btvl1_process([f.cpu().numpy() for f in y], [f.cpu().numpy() for f in flows], 2, p,
+                                             return_full=True)
+    out, full = _solve(y, flows, 2, 0, iterations=4)
+    assert np.array_equal(ref_full, full.cpu().numpy())
+    assert np.array_equal(ref_out, out.cpu().numpy())
+
+
+@pytest.mark.parametrize("rows,cols,iters", [(270, 480, 6), (540, 960, 4)])
+def test_specialised_and_generic_kernels_agree_at_full_size(rows, cols, iters):
+    import torch
+
+    y, flows = _sequence(9, rows, cols, 3, seed=rows)
+    out_f, full_f = _solve(y, flows, 4, 0, iterations=iters)
+    out_g, full_g = _solve(y, flows, 4, 1, iterations=iters)
+    assert torch.equal(full_f, full_g)
+    assert torch.equal(out_f, out_g)
+    assert full_f.shape == (rows * 4, cols * 4, 3) and out_f.shape == (rows * 4 - 14, cols * 4 - 14, 3)
+
+
+def test_fixed_point_at_cfg4_size():
+    import torch
+    from superresolution_amd import ops
+
+    rows, cols, s = 540, 960, 4
+    g = torch.Generator().manual_seed(3)
+    y0 = (torch.rand((rows, cols, 3), generator=g) * 255).cuda()
+    X0 = ops.resize_cubic(y0, rows * s, cols * s)
+    gk = ops.gaussian_kernel(5, 0)
+    zero = torch.zeros((rows, cols, 2), dtype=torch.float32, device="cuda")
+    fm, bm = ops.build_maps(zero, s)
+    # sign(y - D H X0) is 0 exactly where y equals the blurred, decimated X0; the oracle evaluates D H X0 for
+    # one 64x64 tile, and its interior (LR pixels 1..14, which do not see the tile border) is planted in y
+    tile = X0[:64, :64].cpu().numpy()
+    want = oracle.resize_nearest(oracle.sep_filter(tile, gk), 16, 16)
+    ylr = y0.clone()
+    full_sign = ops.forward_sign(X0, bm, ylr, s, gk)
+    ylr[1:15, 1:15] = torch.from_numpy(want[1:15, 1:15]).cuda()
+    sg = ops.forward_sign(X0, bm, ylr, s, gk)
+    words = sg.cpu().numpy()
+    zero_word = int(ops.pack_signs(np.zeros((1, 1, 3)))[0, 0])
+    assert np.all(words[1:15, 1:15] == zero_word)
+    assert np.array_equal(words[20:], full_sign.cpu().numpy()[20:])     # the rest of the image is untouched
+    # with all-zero signs and lambda = 0 the update leaves X where it is
+    allzero = torch.full((rows, cols), zero_word, dtype=torch.int32, device="cuda")
+    w = ops.calc_btv_weights(7, 0.7)
+    X1 = ops.backproject_update(X0, [fm], [allzero], s, gk, 7, w, 1.3, 0.0)
+    assert torch.equal(X1, X0)
+
+
+def test_frame_order_does_not_matter_without_regulariser():
+    """sum_k M_k^T H^T D^T sign_k is a sum of multiples of 1/256: exact in any order (dyadic blur kernel)."""
+    import torch
+
+    rows, cols = 270, 480
+    y, flows = _sequence(5, rows, cols, 3, seed=21)
+    from superresolution_amd import api, ops
+
+    rel = ops.relative_motions(flows, 2, rows, cols)
+    sr = api.BTV_L1()
+    sr.set("iterations", 3)
+    sr.set("lambda", 0.0)
+    a = ops.run(sr, y, rel, 2)
+    perm = [4, 2, 0, 3, 1]
+    b = ops.run(sr, [y[i] for i in perm], [rel[i] for i in perm], perm.index(2))
+    assert torch.equal(a, b)
+
+
+def test_tvl1_at_cfg3_size():
+    import torch
+    from superresolution_amd import api, synth
+
+    rows, cols = 1080, 1920
+    cam = synth.camera_path(1, seed=9)[0]
+    f0 = synth.ground_truth_frame(cam, rows, cols, 1, 9, "cuda")[:, :, 0].float().contiguous()
+    sr = api.BTV_L1()
+    flow, n = sr.calcFlowDevice(f0, f0)
+    assert torch.count_nonzero(flow) == 0
+    # a frame shifted by (+3, -2) pixels: flow(f0 -> f1) = (+3, -2) away from the border
+    f1 = torch.roll(f0, shifts=(-2, 3), dims=(0, 1)).contiguous()
+    flow, n = sr.calcFlowDevice(f0, f1)
+    inner = flow[64:-64, 64:-64]
+    err = (inner - torch.tensor([3.0, -2.0], device="cuda")).abs().mean(dim=(0, 1))
+    assert float(err.max()) < 0.1, err
+    assert 0 < n <= 5 * 5 * 300
