@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not bracket the solver kernels with HIP events (the roofline object is then left out)")
-    ap.add_argument("--cpu-iters", type=int, default=20, help="iterations of the CPU sample solve")
+    ap.add_argument("--cpu-iters", type=int, default=12, help="iterations of the CPU sample solve")
     return ap.parse_args()
 
 
@@ -85,30 +85,44 @@ def measured_traffic(kernel):
 
 def cpu_baseline(args, lr_u8, flows, base):
     """The unfused restatement of the reference CPU path (oracle/, OpenMP over rows) on one window of the same
-    workload, for a bounded number of iterations; scaled to the full iteration count."""
+    workload, for a bounded number of iterations, scaled to the full iteration count; at all host threads the
+    process may use and, on a shorter sample, at one thread."""
     import oracle
 
     y = [f.cpu().numpy().astype(np.float32) for f in lr_u8]
     fl = [f.cpu().numpy() for f in flows]
-    threads = oracle.max_threads()
-    times = {}
-    for it in (1, 1 + args.cpu_iters):
-        p = oracle.BtvParams(scale=args.scale, iterations=it)
-        t0 = time.perf_counter()
-        oracle.btvl1_process(y, fl, base, p)
-        times[it] = time.perf_counter() - t0
-    per_iter = (times[1 + args.cpu_iters] - times[1]) / args.cpu_iters
-    setup = max(times[1] - per_iter, 0.0)
-    frame_s = setup + per_iter * args.iterations
     mpix = args.rows * args.cols * args.scale ** 2 / 1e6
-    return {
-        "value": mpix / frame_s,
+
+    def measure(n_iters):
+        times = {}
+        for it in (1, 1 + n_iters):
+            p = oracle.BtvParams(scale=args.scale, iterations=it)
+            t0 = time.perf_counter()
+            oracle.btvl1_process(y, fl, base, p)
+            times[it] = time.perf_counter() - t0
+        per_iter = (times[1 + n_iters] - times[1]) / n_iters
+        setup = max(times[1] - per_iter, 0.0)
+        return per_iter, setup, mpix / (setup + per_iter * args.iterations)
+
+    threads = oracle.max_threads()
+    per_iter, setup, value = measure(args.cpu_iters)
+    out = {
+        "value": value,
         "unit": "Mpix/s",
         "cores": threads,
         "kind": "port",
         "sample": f"one {len(y)}-frame window of the same workload, {1 + args.cpu_iters} solver iterations timed "
                   f"({per_iter:.2f} s/iteration, {setup:.2f} s set-up), scaled to {args.iterations} iterations",
     }
+    if threads > 1 and args.cpu_iters >= 4:
+        oracle.set_threads(1)
+        try:
+            p1, s1, v1 = measure(1)
+        finally:
+            oracle.set_threads(threads)
+        out["single_thread"] = {"value": v1, "unit": "Mpix/s", "cores": 1,
+                                "sample": f"same window, 2 solver iterations timed ({p1:.2f} s/iteration)"}
+    return out
 
 
 def main():
