@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--iterations", type=int, default=180)
     ap.add_argument("--flow", choices=["synthetic", "tvl1"], default="tvl1",
                     help="motion stage: exact synthetic motion resident in HBM, or the built-in TV-L1 flow")
+    ap.add_argument("--host-io", action="store_true",
+                    help="hand over host frames and take host output (the PCIe-inclusive rate; never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not bracket the solver kernels with HIP events (the roofline object is then left out)")
@@ -172,7 +174,7 @@ def main():
     sr.set("scale", s)
     sr.set("iterations", args.iterations)
     sr.set("temporalAreaRadius", r)
-    sr.set("outputMemory", L.SRX_MEM_DEVICE)
+    sr.set("outputMemory", L.SRX_MEM_HOST if args.host_io else L.SRX_MEM_DEVICE)
     if args.flow == "tvl1":
         sr.setOpticalFlow(api.DualTVL1())
     else:
@@ -184,6 +186,8 @@ def main():
             return f
 
         sr.setOpticalFlow(flow_cb)
+    if args.host_io:
+        left, own, right = ([f.cpu().numpy() for f in v] for v in (left, own, right))
     spans.configure_span(sr, left, own, right)
 
     def step():
@@ -257,6 +261,7 @@ def main():
                             f"temporalAreaRadius {r} (window {K}), streaming nextFrame(), motion: "
                             + ("built-in TV-L1 flow" if args.flow == "tvl1" else "exact synthetic flow resident in HBM"),
                 "frames_per_gpu": args.steps,
+                "io": "host frames in, host frames out (PCIe inclusive)" if args.host_io else "frames resident in HBM",
                 "partition": "contiguous span of output frames per GPU, halo of r LR frames swapped point to point",
                 "halo_exchange_ms": round(halo_ms, 3),
                 "step_ms": [round(v, 2) for v in step_ms],

@@ -40,8 +40,8 @@ int copy_to_device(const srx_image& im, void* dst, hipStream_t st)
 {
     const size_t rowbytes = (size_t)im.cols * im.channels * elem_size(im.depth);
     const size_t step = im.step ? im.step : rowbytes;
-    SRX_HIP(hipMemcpy2DAsync(dst, rowbytes, im.data, step, rowbytes, im.rows,
-                             im.mem == SRX_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
+    SRX_HIP(copy_pitched(dst, rowbytes, im.data, step, rowbytes, im.rows,
+                         im.mem == SRX_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
     return SRX_OK;
 }
 
@@ -50,8 +50,8 @@ int copy_from_device(const void* src, const srx_image& im, hipStream_t st)
 {
     const size_t rowbytes = (size_t)im.cols * im.channels * elem_size(im.depth);
     const size_t step = im.step ? im.step : rowbytes;
-    SRX_HIP(hipMemcpy2DAsync(im.data, step, src, rowbytes, rowbytes, im.rows,
-                             im.mem == SRX_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+    SRX_HIP(copy_pitched(im.data, step, src, rowbytes, rowbytes, im.rows,
+                         im.mem == SRX_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
     return SRX_OK;
 }
 

@@ -201,8 +201,8 @@ int device_view(const srx_image& im, DeviceBuffer& tmp, const void** ptr, size_t
     }
     if (int rc = tmp.reserve(rowbytes * im.rows))
         return rc;
-    SRX_HIP(hipMemcpy2DAsync(tmp.get(), rowbytes, im.data, im.step ? im.step : rowbytes, rowbytes, im.rows,
-                             hipMemcpyHostToDevice, st));
+    SRX_HIP(copy_pitched(tmp.get(), rowbytes, im.data, im.step ? im.step : rowbytes, rowbytes, im.rows,
+                         hipMemcpyHostToDevice, st));
     *ptr = tmp.get();
     *step = rowbytes;
     return SRX_OK;

@@ -627,8 +627,8 @@ int Tvl1::calc_images(const srx_image& f0, const srx_image& f1, const Tvl1Params
         if (int rc = raw[i]->reserve(rowbytes * rows))
             return rc;
         const size_t step = fr[i]->step ? fr[i]->step : rowbytes;
-        SRX_HIP(hipMemcpy2DAsync(raw[i]->get(), rowbytes, fr[i]->data, step, rowbytes, rows,
-                                 fr[i]->mem == SRX_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
+        SRX_HIP(copy_pitched(raw[i]->get(), rowbytes, fr[i]->data, step, rowbytes, rows,
+                             fr[i]->mem == SRX_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_to_gray, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, st, raw[i]->get(), px, ch,
                            f0.depth == SRX_32F ? 1 : 0, gray[i]);
         SRX_LAUNCH_CHECK("to_gray");
