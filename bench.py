@@ -231,7 +231,7 @@ def main():
         default_workload = (args.rows, args.cols, args.channels, s, r) == (540, 960, 3, 4, 4)
         kernels = {}
         for name, what, nbytes, secs in (
-                ("k_forward_sign_s4", "sign(y_k - D H M_k X) of all window frames", bytes_fwd, fwd_launch_s),
+                ("k_forward_sign_lds", "sign(y_k - D H M_k X) of all window frames", bytes_fwd, fwd_launch_s),
                 ("k_backproject_update_s4", "back-projection of all window frames + BTV + update", bytes_bwd,
                  bwd_launch_s)):
             traffic, traffic_src = measured_traffic(name) if default_workload else (None, None)
@@ -240,8 +240,8 @@ def main():
                              "traffic_source": traffic_src, "algorithmic_bytes_per_launch": nbytes,
                              "avg_launch_us": secs * 1e6}
         # the dominant kernel is the one the solver spends more time in
-        dominant = "k_forward_sign_s4" if fwd_launch_s >= bwd_launch_s else "k_backproject_update_s4"
-        other = "k_backproject_update_s4" if dominant == "k_forward_sign_s4" else "k_forward_sign_s4"
+        dominant = "k_forward_sign_lds" if fwd_launch_s >= bwd_launch_s else "k_backproject_update_s4"
+        other = "k_backproject_update_s4" if dominant == "k_forward_sign_lds" else "k_forward_sign_lds"
         line = {
             "metric": "output Mpix/s, BTV-L1 4x 960x540->4K, 1/2/4/8 GPUs; % HBM roofline",
             "value": world * args.steps * mpix / elapsed,

@@ -16,16 +16,13 @@
 //                 cv::remap(INTER_NEAREST) derives from its float map.
 //   decoded maps  one uint32 per HR pixel, derived from the raw maps for the
 //                 specialised kernels:
-//                   backward: linear source pixel index, or rows*cols (the
-//                             zero pixel) when the source is outside; behind
-//                             the rows*cols entries follows the group map, two
-//                             words per 4 pixels of a row (kGrp* below), laid
-//                             out per LR pixel (y, x): first all "word 0", four
-//                             per LR pixel, for HR rows 4y-1 .. 4y+2 (reflected
-//                             at the top) and columns 4x .. 4x+3, then all
-//                             "word 1" in the same order - the forward kernel
-//                             reads an LR pixel's four rows with two 16-byte
-//                             loads;
+//                   backward: the group map, two words per 4 pixels of a
+//                             row (kGrp* below), laid out per LR pixel (y, x):
+//                             first all "word 0", four per LR pixel, for HR
+//                             rows 4y-1 .. 4y+2 (reflected at the top) and
+//                             columns 4x .. 4x+3, then all "word 1" in the
+//                             same order - the forward kernel reads an LR
+//                             pixel's four rows with two 16-byte loads;
 //                   forward:  see kFwd* below.
 //   signs         one uint32 word per LR pixel and window frame: sign+1 (0,1,2)
 //                 of channel c in bits 10c..10c+1.  Generic kernels keep a
@@ -59,12 +56,15 @@ namespace
 //                left and top edges, which therefore need no entries of their
 //                own); 25 = all weights 0 (target outside the image, or in the
 //                last column / row, whose only tap is a reflected one)
-// group map entry of the backward map, for entries m0..m3 of 4 neighbouring pixels:
-//   word 0  bits 0..29 m0; bit 31: m1..m3 = m0+1..m0+3 (one run of source pixels);
-//           bit 30: some entry is further from the run than word 1 can say (use the full map)
-//   word 1  for i = 1..3, at bit 10(i-1): dx (5 bits, signed), then dy (5 bits, signed), with
-//           m_i = m0 + i + dx + dy * cols
-constexpr uint32_t kGrpRun = 1u << 31, kGrpFar = 1u << 30, kGrpIndexMask = (1u << 30) - 1;
+// group map entry of the backward map, for the sources (col_i, row_i), i = 0..3, of 4 neighbouring
+// pixels of HR row N = 4y-1+r (the map row itself is the reflected one at the top edge), columns 4x..4x+3:
+//   word 0  bits 0..14 col_0 - 4x, bits 15..29 row_0 - N, both signed;
+//           bit 30: "far" - some coordinate does not fit its field (read the raw map instead)
+//   word 1  for i = 1..3, at bit 10(i-1): col_i - (col_0 + i) (5 bits, signed), then row_i - row_0
+//           (5 bits, signed); all zero when the four sources are one run of pixels
+// Sources outside the image keep their coordinates: the forward kernel stages zeros around the image.
+constexpr uint32_t kGrpFar = 1u << 30;
+constexpr int kGrpMaxDim = 16383; // displacements must fit 15 signed bits
 constexpr uint32_t kFwdCellMask = 0x00FFFFFFu;
 constexpr int kFwdLutShift = 24;
 constexpr uint32_t kFwdLutZero = 25;
@@ -186,10 +186,6 @@ __device__ __forceinline__ void cubic_sample(const float* __restrict__ src, int 
 }
 
 // decoded map entries (layout at the top of this file); w = C / 4 LR columns
-__device__ __forceinline__ uint32_t decode_bwd(int bx, int by, int R, int C)
-{
-    return ((unsigned)bx < (unsigned)C && (unsigned)by < (unsigned)R) ? (uint32_t)(by * C + bx) : (uint32_t)(R * C);
-}
 __device__ __forceinline__ uint32_t decode_fwd(int fx, int fy, int R, int C)
 {
     if ((unsigned)fx >= (unsigned)(C - 1) || (unsigned)fy >= (unsigned)(R - 1))
@@ -204,8 +200,7 @@ __device__ __forceinline__ uint32_t decode_fwd(int fx, int fy, int R, int C)
 // (lib/src/btv_l1.cpp:59-101; cv::remap INTER_NEAREST), plus the decoded maps
 // for the specialised kernels when dec_fwd / dec_bwd are given (scale 4 only).
 __global__ void k_build_maps(const float* __restrict__ rel, int rows, int cols, int scale, CubicTables t,
-                             short2* __restrict__ fwd_map, short2* __restrict__ bwd_map, uint32_t* __restrict__ dec_fwd,
-                             uint32_t* __restrict__ dec_bwd)
+                             short2* __restrict__ fwd_map, short2* __restrict__ bwd_map, uint32_t* __restrict__ dec_fwd)
 {
     const int R = rows * scale, C = cols * scale;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -221,29 +216,23 @@ __global__ void k_build_maps(const float* __restrict__ rel, int rows, int cols, 
     const size_t o = (size_t)y * C + x;
     fwd_map[o] = make_short2((short)fx, (short)fy);
     bwd_map[o] = make_short2((short)bx, (short)by);
-    if (dec_bwd)
-        dec_bwd[o] = decode_bwd(bx, by, R, C);
     if (dec_fwd)
         dec_fwd[o] = decode_fwd(fx, fy, R, C);
 }
 
 // raw int16 maps -> decoded maps (same rules as k_build_maps), for callers that hold raw maps only
-__global__ void k_decode_maps(const short2* __restrict__ fwd_map, const short2* __restrict__ bwd_map, int R, int C,
-                              uint32_t* __restrict__ dec_fwd, uint32_t* __restrict__ dec_bwd)
+__global__ void k_decode_maps(const short2* __restrict__ fwd_map, int R, int C, uint32_t* __restrict__ dec_fwd)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= C || y >= R)
         return;
     const size_t o = (size_t)y * C + x;
-    if (dec_bwd)
-        dec_bwd[o] = decode_bwd(bwd_map[o].x, bwd_map[o].y, R, C);
-    if (dec_fwd)
-        dec_fwd[o] = decode_fwd(fwd_map[o].x, fwd_map[o].y, R, C);
+    dec_fwd[o] = decode_fwd(fwd_map[o].x, fwd_map[o].y, R, C);
 }
 
-// group map behind the decoded backward map (layout at the top of this file); one thread per entry
-__global__ void k_group_maps(uint32_t* __restrict__ dec_bwd, int H, int W)
+// group map of the backward map (layout at the top of this file); one thread per entry
+__global__ void k_group_maps(const short2* __restrict__ bwd_map, uint32_t* __restrict__ grp, int H, int W)
 {
     const int w = W >> 2, h = H >> 2;
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -253,29 +242,65 @@ __global__ void k_group_maps(uint32_t* __restrict__ dec_bwd, int H, int W)
     const int r = (int)(e & 3);
     const size_t cell = e >> 2;
     const int x = (int)(cell % w), y = (int)(cell / w);
-    const int Y = reflect101(4 * y - 1 + r, H);
-    const uint4 m = *(const uint4*)(dec_bwd + (size_t)Y * W + 4 * x);
-    const uint32_t mi[3] = {m.y, m.z, m.w};
-    uint32_t w0 = m.x, w1 = 0;
-    bool run = true, far = false;
+    const int N = 4 * y - 1 + r;
+    const short2* m = bwd_map + (size_t)reflect101(N, H) * W + 4 * x;
+    const int col0 = m[0].x, row0 = m[0].y;
+    const int ddx = clampi(col0 - 4 * x, -16384, 16383), ddy = clampi(row0 - N, -16384, 16383);
+    bool far = ddx != col0 - 4 * x || ddy != row0 - N;
+    uint32_t w1 = 0;
     for (int i = 1; i <= 3; ++i)
     {
-        const int d = (int)(mi[i - 1] - m.x) - i; // distance from the run that starts at m0
-        run = run && d == 0;
-        // d = dy * W + dx with |dx|, |dy| <= 15 (unique once W > 30)
-        int dy = (abs(d) + W / 2) / W;
-        dy = d < 0 ? -dy : dy;
-        const int dx = d - dy * W;
-        far = far || W <= 30 || dx < -15 || dx > 15 || dy < -15 || dy > 15;
+        const int dx = m[i].x - (col0 + i), dy = m[i].y - row0;
+        far = far || dx < -16 || dx > 15 || dy < -16 || dy > 15;
         w1 |= ((uint32_t)(dx & 31) | ((uint32_t)(dy & 31) << 5)) << (10 * (i - 1));
     }
-    if (run)
-        w0 |= kGrpRun;
-    else if (far)
-        w0 |= kGrpFar;
-    uint32_t* grp = dec_bwd + (size_t)H * W;
-    grp[e] = w0;
+    grp[e] = ((uint32_t)ddx & 0x7FFFu) | (((uint32_t)ddy & 0x7FFFu) << 15) | (far ? kGrpFar : 0u);
     grp[entries + e] = w1;
+}
+
+// Geometry of the forward kernel's LDS window (described above k_forward_sign_lds)
+constexpr int kFwdStrip = 63;
+constexpr int kFwdRing = 40;
+constexpr int kFwdMy = 15;
+constexpr int kFwdMx = 16;
+constexpr int kFwdQuads = kFwdStrip + 1 + kFwdMx / 2; // 16-byte groups per staged row
+constexpr int kFwdRowBytes = 16 * kFwdQuads;          // one row of one plane
+constexpr int kFwdSpan = 5 + 2 * kFwdMy;              // HR rows an LR row may read
+constexpr int kFwdMaxWaves = 9;                       // window frames per block
+static_assert(kFwdSpan + 4 <= kFwdRing && 2 * kFwdMy + 8 < kFwdRing,
+              "rows staged during an LR row must not replace rows that row or the next one reads");
+static_assert(kFwdMx % 4 == 0, "staged columns start at a multiple of four");
+
+// One flag byte per (LR row, strip) of a frame's group map: 1 when every pixel the forward kernel
+// gathers for that row of that strip lies inside its LDS window and no group is "far", so that the
+// kernel may skip the checks.  One wave per (strip, LR row); lanes as in the forward kernel.
+__global__ void k_group_flags(const uint32_t* __restrict__ grp, uint8_t* __restrict__ flags, int H, int W, int strips_x)
+{
+    const int w = W >> 2, h = H >> 2;
+    const int strip = blockIdx.x, y = blockIdx.y, lane = threadIdx.x;
+    const int x0 = strip * kFwdStrip;
+    const int xl = min(max(x0 - 1 + lane, 0), w - 1);
+    const int dc_lane = 4 * xl - (4 * (x0 - 1) - kFwdMx);
+    const size_t entries = (size_t)h * w * 4;
+    bool ok = true;
+    for (int r = 0; r < 4; ++r)
+    {
+        const size_t e = ((size_t)y * w + xl) * 4 + r;
+        const uint32_t w0 = grp[e];
+        const int w1 = (int)grp[entries + e];
+        const int dr = __builtin_amdgcn_sbfe((int)w0, 15, 15) + kFwdMy + 1 + r;
+        const int dc = __builtin_amdgcn_sbfe((int)w0, 0, 15) + dc_lane;
+        ok = ok && (w0 & kGrpFar) == 0 && (unsigned)dr < (unsigned)kFwdSpan && (unsigned)dc < (unsigned)(4 * kFwdQuads);
+        for (int j = 1; j < 4; ++j)
+        {
+            const int drj = dr + __builtin_amdgcn_sbfe(w1, 10 * (j - 1) + 5, 5);
+            const int e_ = dc + j + __builtin_amdgcn_sbfe(w1, 10 * (j - 1), 5);
+            ok = ok && (unsigned)drj < (unsigned)kFwdSpan && (unsigned)e_ < (unsigned)(4 * kFwdQuads);
+        }
+    }
+    const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
+    if (lane == 0)
+        flags[(size_t)y * strips_x + strip] = all_ok ? 1 : 0;
 }
 
 // ps == 0: interleaved destination; otherwise planar with plane stride ps
@@ -622,114 +647,238 @@ template <int N> struct __attribute__((packed, aligned(4))) packed_floats
     float v[N];
 };
 
-// Forward chain sign(y_k - D H M_k X), one wave per (strip of 63 LR columns,
-// group of LR rows, window frame).  X is planar.
+// Forward chain sign(y_k - D H M_k X) with the gathers served from LDS.
 //
-// Lane l works on LR column x = x0 - 1 + l and holds, per HR row and plane, the
-// warped pixels of HR columns 4x .. 4x+3: one aligned 16-byte read of four
-// backward-map entries, then - when the four entries are consecutive source
-// pixels, the common case for smooth motion - one 16-byte gather per plane;
-// lanes whose entries break fetch the other three pixels one by one.  The 5-tap
-// row pass centred on column 4x is
+// One block per tile (strip of 63 LR columns x a range of LR rows), one wave per window frame.
+// Every frame of the window gathers from nearly the same region of X - the motions are a few
+// pixels - so the block keeps that region in LDS and X leaves the caches once per tile instead of
+// once per frame: a ring of kFwdRing HR rows x (strip + kFwdMx columns either side), all planes,
+// walks down the tile, four new HR rows per LR row, staged by all waves with aligned 16-byte loads
+// (zeros around the image: cv::remap's constant border).  An LR row may read the HR rows
+// 4y-2-kFwdMy .. 4y+2+kFwdMy; a lane with a source outside that window, or with a "far" group,
+// re-reads its four pixels from global memory, so the window only decides speed, never values.
+//
+// LDS layout of one staged row and plane: four sub-arrays, one per column phase (column & 3), of
+// kFwdQuads floats each.  Neighbouring lanes read pixels four columns apart, i.e. neighbouring
+// elements of one sub-array: no bank conflicts, whatever the alignment of the motion.
+//
+// Lane l works on LR column x = x0 - 1 + l and holds, per HR row and plane, the warped pixels of HR
+// columns 4x .. 4x+3.  The 5-tap row pass centred on column 4x is
 //     a0*k0 + (L.a3 + a1)*k1 + (L.a2 + a2)*k2
-// with L the lane to the left (lane 0 only serves as lane 1's left neighbour;
-// at the image's left edge reflect101 maps columns -1, -2 to a1, a2).  The wave
-// walks down its LR rows keeping the five row-pass results of the current LR
-// row in registers (four new HR rows per LR row); the map entries of the next
-// LR row are fetched while the current one is gathered.
-// Signs go to the pair plane (layout at the top of this file).
-// Work items are ordered frame-fastest so that the waves gathering from one
-// region of X run together on one CU / XCD.
-#ifndef SRX_A_ROWS
-#define SRX_A_ROWS 6
+// with L the lane to the left (lane 0 only serves as lane 1's left neighbour; at the image's left
+// edge reflect101 maps columns -1, -2 to a1, a2).  The wave walks down its LR rows keeping the five
+// row-pass results of the current LR row in registers (four new HR rows per LR row).  Signs go to
+// the pair plane (layout at the top of this file).
+// The ring is re-used with one barrier per LR row: rows staged during LR row y replace rows that
+// neither row y nor row y+1 reads (static_assert below).
+#ifndef SRX_A2_WAVES
+#define SRX_A2_WAVES 3
 #endif
-#ifndef SRX_A_WAVES
-#define SRX_A_WAVES 3
-#endif
-#ifndef SRX_A_WPB
-#define SRX_A_WPB 1 // waves (work items) per block: single-wave blocks pack the SIMDs best
-#endif
-constexpr int kFwdRowsPerWave = SRX_A_ROWS;
-constexpr int kFwdStrip = 63;
+
+inline size_t forward_lds_bytes(int ch)
+{
+    return (size_t)kFwdRing * ch * kFwdRowBytes;
+}
 
 template <int CH>
-__global__ __launch_bounds__(64 * SRX_A_WPB, SRX_A_WAVES) void k_forward_sign_s4(const float* __restrict__ X, int H, int W,
-                                                                       size_t ps, PtrList dec_bwd, PtrList ys,
-                                                                       MutPtrList signs, int K, GaussK g, int strips_x,
-                                                                       unsigned n_items, unsigned n_blocks)
+__global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sign_lds(
+    const float* __restrict__ X, int H, int W, size_t ps, PtrList raw_bwd, PtrList grp_bwd, PtrList ys, MutPtrList signs,
+    int K, GaussK g, int strips_x, int rows_per_tile, unsigned n_tiles)
 {
-    const unsigned item = xcd_contiguous(blockIdx.x, n_blocks) * SRX_A_WPB + (threadIdx.x >> 6);
-    if (item >= n_items)
+    extern __shared__ __align__(16) char ring[];
+    constexpr int kSlotBytes = CH * kFwdRowBytes;
+    constexpr int kItemsPerRow = CH * kFwdQuads;
+    constexpr int kRingBytes = kFwdRing * kSlotBytes;
+
+    const unsigned tile = xcd_contiguous(blockIdx.x, n_tiles);
+    if (tile >= n_tiles)
         return;
-    const int k = item % K;
-    const unsigned tile = item / K;
+    if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring != 0u)
+        __builtin_trap(); // the gathers below address the ring by offset
     const int strip = tile % strips_x, rg = tile / strips_x;
     const int h = H >> 2, w = W >> 2;
-    const int lane = threadIdx.x & 63;
-    const int x0 = strip * kFwdStrip, y0 = rg * kFwdRowsPerWave;
-    const int y1 = min(y0 + kFwdRowsPerWave, h);
+    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+    const int kw = blockIdx.y * (nthreads >> 6) + (tid >> 6);
+    const bool active = kw < K;
+    // a spare wave shadows frame 0 (it still stages and meets the barriers); wave-uniform, so that
+    // everything derived from the frame's pointers stays in scalar registers
+    const int k = __builtin_amdgcn_readfirstlane(active ? kw : 0);
+    const int x0 = strip * kFwdStrip, y0 = rg * rows_per_tile;
+    const int y1 = min(y0 + rows_per_tile, h);
 
     const int x = x0 - 1 + lane;          // LR column of this lane
     const int xl = min(max(x, 0), w - 1); // column it loads (clamped copies are never stored)
-    const bool owner = lane >= 1 && x < w;
+    const bool owner = active && lane >= 1 && x < w;
     const bool first = x == 0;
 
-    const uint32_t* map = (const uint32_t*)dec_bwd.p[k] + 4 * xl;      // full entries (lanes with a break only)
-    // group map: word 0 and word 1 of this LR column's four rows, 16 bytes each per LR row
-    const uint4* grp0 = (const uint4*)((const uint32_t*)dec_bwd.p[k] + (size_t)H * W) + xl;
+    const int c0 = 4 * (x0 - 1) - kFwdMx;  // HR column of element 0 of the staged rows
+    const int rbase = 4 * y0 - 2 - kFwdMy; // HR row in ring slot 0
+    const int dc_lane = 4 * xl - c0;
+
+    const uint4* grp0 = (const uint4*)grp_bwd.p[k] + xl;
     const uint4* grp1 = grp0 + (size_t)h * w;
+    // per LR row: 1 = every gather of this strip's row stays inside the window (k_group_flags)
+    const uint8_t* flags = (const uint8_t*)((const uint32_t*)grp_bwd.p[k] + (size_t)H * W / 2) + strip;
     const float* yk = (const float*)ys.p[k] + (size_t)xl * CH;
     uint32_t* sp = (uint32_t*)signs.p[k] + 2 * (size_t)xl;
     const float k0 = g.k[2], k1 = g.k[3], k2 = g.k[4];
 
-    // entries of HR rows 4y-1 .. 4y+2
+    // ---- staging -----------------------------------------------------------------------------
+    // piece -> (row within the batch, plane, 16-byte group)
+    auto stage_piece = [&](int item, int row_first, int slot_first) {
+        const int rr_ = item / kItemsPerRow, rem = item - rr_ * kItemsPerRow;
+        const int c = rem / kFwdQuads, q = rem - c * kFwdQuads;
+        const int row = row_first + rr_, col = c0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)row < (unsigned)H && (unsigned)col < (unsigned)W)
+            v = *(const float4*)(X + c * ps + (size_t)row * W + col);
+        const int slot = (slot_first + rr_) % kFwdRing;
+        float* d = (float*)(ring + slot * kSlotBytes + c * kFwdRowBytes) + q;
+        d[0] = v.x, d[kFwdQuads] = v.y, d[2 * kFwdQuads] = v.z, d[3 * kFwdQuads] = v.w;
+    };
+    for (int item = tid; item < kFwdSpan * kItemsPerRow; item += nthreads)
+        stage_piece(item, rbase, 0);
+
+    // Pieces of this thread within a batch of four HR rows (fixed for the whole tile).  Blocks of
+    // many waves (the common case) own at most two pieces per batch and load them a whole LR row
+    // before they are written to LDS; blocks of few waves stage piece by piece.
+    const bool early = 2 * nthreads >= 4 * kItemsPerRow;
+    int p_rr[2], p_lds[2];
+    size_t p_src[2];
+    bool p_own[2], p_col[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+    {
+        const int item = tid + i * nthreads;
+        const int rr_ = item / kItemsPerRow, rem = item - rr_ * kItemsPerRow;
+        const int c = rem / kFwdQuads, q = rem - c * kFwdQuads;
+        const int col = c0 + 4 * q;
+        p_own[i] = early && item < 4 * kItemsPerRow;
+        p_col[i] = (unsigned)col < (unsigned)W;
+        p_rr[i] = rr_;
+        p_lds[i] = c * kFwdRowBytes + 4 * q;
+        p_src[i] = c * ps + (size_t)(p_col[i] ? col : 0);
+    }
+    auto batch_load = [&](int row_first, float4 (&v)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+        {
+            const int row = row_first + p_rr[i];
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p_own[i] && p_col[i] && (unsigned)row < (unsigned)H)
+                v[i] = *(const float4*)(X + p_src[i] + (size_t)row * W);
+        }
+    };
+    auto batch_put = [&](int slot_first, const float4 (&v)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (p_own[i])
+            {
+                int slot = slot_first + p_rr[i];
+                slot = (int)min((unsigned)slot, (unsigned)(slot - kFwdRing));
+                float* d = (float*)(ring + slot * kSlotBytes + p_lds[i]);
+                d[0] = v[i].x, d[kFwdQuads] = v[i].y, d[2 * kFwdQuads] = v[i].z, d[3 * kFwdQuads] = v[i].w;
+            }
+    };
+
     auto load_groups = [&](int y, uint2 (&m)[4]) {
         const uint4 a0 = stream_load(grp0 + (size_t)y * w), a1 = stream_load(grp1 + (size_t)y * w);
         m[0] = make_uint2(a0.x, a1.x), m[1] = make_uint2(a0.y, a1.y);
         m[2] = make_uint2(a0.z, a1.z), m[3] = make_uint2(a0.w, a1.w);
     };
-    auto consecutive = [](const uint2& gm) { return (gm.x & kGrpRun) != 0; };
-    auto gather = [&](const uint2& gm, float4 (&a)[CH]) {
+    // The four pixels of one group (HR row N of this lane's LR column), every plane.  `dr0` is row
+    // N's place in the current window, `s` the ring slot of the window's first row.  Returns false
+    // when some pixel is not in the window (the values are then to be replaced by fetch_global).
+    // The ring is the kernel's only LDS object, so its addresses are plain byte offsets.
+    typedef const float __attribute__((address_space(3))) lds_cfloat;
+    auto fetch = [&](const uint2& gm, int dr0, int s, bool checked, float4 (&a)[CH]) -> bool {
+        const int dr = __builtin_amdgcn_sbfe((int)gm.x, 15, 15) + dr0;
+        const int dc = __builtin_amdgcn_sbfe((int)gm.x, 0, 15) + dc_lane;
+        const int w1 = (int)gm.y;
+        // sources in other rows than the first pixel's are rare: one branch for the whole wave
+        const bool rows_differ = __builtin_amdgcn_ballot_w64((w1 & 0x3E0F83E0) != 0) != 0;
+        unsigned far_row = (unsigned)dr, far_col = (unsigned)dc; // unsigned maxima: negatives count as huge
+        float v[4][CH];
+        auto pixel = [&](int j, unsigned row_at, unsigned e) {
+            // element e of the row: sub-array e & 3, index e >> 2, i.e. byte e + (e & 3) * (4 * kFwdQuads - 1)
+            unsigned at = __umul24(e & 3u, (unsigned)(4 * kFwdQuads - 1)) + (e + row_at);
+            if (checked) // stay inside the ring, whatever the entry says
+                at = min(at, (unsigned)(kRingBytes - (CH - 1) * kFwdRowBytes - 4));
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                v[j][c] = *(lds_cfloat*)(uintptr_t)(at + c * kFwdRowBytes);
+        };
+        auto row_offset = [&](int drj) {
+            int slot = s + drj;
+            slot = (int)min((unsigned)slot, (unsigned)(slot - kFwdRing));
+            return __umul24((unsigned)slot, (unsigned)kSlotBytes);
+        };
+        if (!rows_differ)
+        {
+            const unsigned row_at = row_offset(dr);
+            pixel(0, row_at, (unsigned)dc);
+#pragma unroll
+            for (int j = 1; j < 4; ++j)
+            {
+                const unsigned e = (unsigned)(dc + j + __builtin_amdgcn_sbfe(w1, 10 * (j - 1), 5));
+                if (checked)
+                    far_col = max(far_col, e);
+                pixel(j, row_at, e);
+            }
+        }
+        else
+        {
+            pixel(0, row_offset(dr), (unsigned)dc);
+#pragma unroll
+            for (int j = 1; j < 4; ++j)
+            {
+                const int drj = dr + __builtin_amdgcn_sbfe(w1, 10 * (j - 1) + 5, 5);
+                const unsigned e = (unsigned)(dc + j + __builtin_amdgcn_sbfe(w1, 10 * (j - 1), 5));
+                if (checked)
+                    far_row = max(far_row, (unsigned)drj), far_col = max(far_col, e);
+                pixel(j, row_offset(drj), e);
+            }
+        }
 #pragma unroll
         for (int c = 0; c < CH; ++c)
-        {
-            const float4_a4 v = *(const float4_a4*)(X + c * ps + (gm.x & kGrpIndexMask));
-            a[c] = make_float4(v.x, v.y, v.z, v.w);
-        }
+            a[c] = make_float4(v[0][c], v[1][c], v[2][c], v[3][c]);
+        return !checked ||
+               ((gm.x & kGrpFar) == 0 && far_row < (unsigned)kFwdSpan && far_col < (unsigned)(4 * kFwdQuads));
     };
-    // Lanes whose entries are not one run fetch the other three pixels one by one.  The values land
-    // in registers of their own and are merged afterwards: a load into a register that an earlier
-    // load still has to fill would wait for that load, and the gathers of a row are meant to be in
-    // flight together.
-    auto patch_load = [&](const uint2& gm, int Y, float (&t)[CH][3]) {
-        uint4 m;
-        m.x = gm.x & kGrpIndexMask;
+    auto fetch_global = [&](const uint2& gm, int N, float4 (&a)[CH]) {
+        int col[4], row[4];
         if (gm.x & kGrpFar)
-            m = *(const uint4*)(map + (size_t)reflect101(Y, H) * W);
+        {
+            const short2* m = (const short2*)raw_bwd.p[k] + (size_t)reflect101(N, H) * W + 4 * xl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                col[j] = m[j].x, row[j] = m[j].y;
+        }
         else
         {
             const int w1 = (int)gm.y;
-            m.y = m.x + 1 + __builtin_amdgcn_sbfe(w1, 0, 5) + __builtin_amdgcn_sbfe(w1, 5, 5) * W;
-            m.z = m.x + 2 + __builtin_amdgcn_sbfe(w1, 10, 5) + __builtin_amdgcn_sbfe(w1, 15, 5) * W;
-            m.w = m.x + 3 + __builtin_amdgcn_sbfe(w1, 20, 5) + __builtin_amdgcn_sbfe(w1, 25, 5) * W;
+            col[0] = 4 * xl + __builtin_amdgcn_sbfe((int)gm.x, 0, 15);
+            row[0] = N + __builtin_amdgcn_sbfe((int)gm.x, 15, 15);
+#pragma unroll
+            for (int j = 1; j < 4; ++j)
+            {
+                col[j] = col[0] + j + __builtin_amdgcn_sbfe(w1, 10 * (j - 1), 5);
+                row[j] = row[0] + __builtin_amdgcn_sbfe(w1, 10 * (j - 1) + 5, 5);
+            }
+        }
+        float v[4][CH];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+            const bool inside = (unsigned)col[j] < (unsigned)W && (unsigned)row[j] < (unsigned)H;
+            const size_t idx = inside ? (size_t)row[j] * W + col[j] : (size_t)H * W; // the zero pixel
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                v[j][c] = X[c * ps + idx];
         }
 #pragma unroll
         for (int c = 0; c < CH; ++c)
-        {
-            t[c][0] = X[c * ps + m.y];
-            t[c][1] = X[c * ps + m.z];
-            t[c][2] = X[c * ps + m.w];
-        }
-    };
-    auto patch_merge = [&](const uint2& gm, const float (&t)[CH][3], float4 (&a)[CH]) {
-        const bool run = consecutive(gm);
-#pragma unroll
-        for (int c = 0; c < CH; ++c)
-        {
-            a[c].y = run ? a[c].y : t[c][0];
-            a[c].z = run ? a[c].z : t[c][1];
-            a[c].w = run ? a[c].w : t[c][2];
-        }
+            a[c] = make_float4(v[0][c], v[1][c], v[2][c], v[3][c]);
     };
     auto row_pass = [&](const float4 (&a)[CH], float (&out)[CH]) {
 #pragma unroll
@@ -738,75 +887,76 @@ __global__ __launch_bounds__(64 * SRX_A_WPB, SRX_A_WAVES) void k_forward_sign_s4
             float l3 = from_left_lane(a[c].w), l2 = from_left_lane(a[c].z);
             l3 = first ? a[c].y : l3;
             l2 = first ? a[c].z : l2;
-            float s = a[c].x * k0;
-            s += (l3 + a[c].y) * k1;
-            s += (l2 + a[c].z) * k2;
-            out[c] = s;
+            float sum = a[c].x * k0;
+            sum += (l3 + a[c].y) * k1;
+            sum += (l2 + a[c].z) * k2;
+            out[c] = sum;
         }
     };
 
     float rr[5][CH];
     uint2 mc[4];
+    const int ya = max(y0 - 1, 0);
+    const uint2 m0 = make_uint2(((const uint32_t*)(grp0 + (size_t)ya * w))[3], ((const uint32_t*)(grp1 + (size_t)ya * w))[3]);
+    load_groups(y0, mc);
+    __syncthreads();
     {
-        // HR row 4*y0 - 2 is the last of the LR row above (for y0 = 0 it reflects to row 2, the last of LR row 0)
-        const int ya = max(y0 - 1, 0);
-        const uint2 m0 = make_uint2(((const uint32_t*)(grp0 + (size_t)ya * w))[3], ((const uint32_t*)(grp1 + (size_t)ya * w))[3]);
-        load_groups(y0, mc);
+        // HR row 4*y0 - 2 is the last of the LR row above (for y0 = 0 it reflects to row 2, the last of
+        // LR row 0); its group's own row is N = 4*ya + 2
+        const int N = 4 * ya + 2;
         float4 a[CH];
-        float t[CH][3] = {};
-        gather(m0, a);
-        if (!consecutive(m0))
-            patch_load(m0, 4 * y0 - 2, t);
-        patch_merge(m0, t, a);
+        if (!fetch(m0, N - rbase, 0, true, a))
+            fetch_global(m0, N, a);
         row_pass(a, rr[0]);
     }
+
+    // The rows that LR row y+1 adds to the window, its map entries and its LR pixel are loaded at
+    // the top of row y and used at its end / in row y+1.
+    int s = 0; // ring slot of the first row of the current LR row's window
+    packed_floats<CH> yv = *(const packed_floats<CH>*)(yk + (size_t)y0 * w * CH);
+    bool inside = flags[(size_t)y0 * strips_x] != 0;
     for (int y = y0; y < y1; ++y)
     {
+        const bool more = y + 1 < y1;
+        const bool inside_next = flags[(size_t)min(y + 1, h - 1) * strips_x] != 0;
+        float4 sv[2];
+        batch_load(more ? 4 * y + 3 + kFwdMy : H, sv);
         uint2 mn[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            mn[r] = mc[r];
-        if (y + 1 < y1)
-            load_groups(y + 1, mn);
-        float yv[CH];
-        {
-            const packed_floats<CH> v = *(const packed_floats<CH>*)(yk + (size_t)y * w * CH);
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-                yv[c] = v.v[c];
-        }
+        load_groups(min(y + 1, h - 1), mn);
+        const packed_floats<CH> yn = *(const packed_floats<CH>*)(yk + (size_t)min(y + 1, h - 1) * w * CH);
 
-        float4 a[4][CH];
-        float t[4][CH][3] = {};
-        bool broken = false;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
+        if (inside)
         {
-            gather(mc[r], a[r]);
-            broken = broken || !consecutive(mc[r]);
+            // all LDS reads of the LR row in flight before the first row pass
+            float4 a[4][CH];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                fetch(mc[r], kFwdMy + 1 + r, s, false, a[r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                row_pass(a[r], rr[r + 1]);
         }
-        if (broken)
+        else
         {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (!consecutive(mc[r]))
-                    patch_load(mc[r], 4 * y - 1 + r, t[r]);
+            {
+                float4 a[CH];
+                if (!fetch(mc[r], kFwdMy + 1 + r, s, true, a))
+                    fetch_global(mc[r], 4 * y - 1 + r, a);
+                row_pass(a, rr[r + 1]);
+            }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            patch_merge(mc[r], t[r], a[r]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            row_pass(a[r], rr[r + 1]);
+        inside = inside_next;
 
         uint32_t sg = 0;
 #pragma unroll
         for (int c = 0; c < CH; ++c)
         {
-            float s = rr[2][c] * k0;
-            s += (rr[1][c] + rr[3][c]) * k1;
-            s += (rr[0][c] + rr[4][c]) * k2;
-            sg |= (uint32_t)((int)dsign(yv[c], s) + 1) << (10 * c);
+            float sum = rr[2][c] * k0;
+            sum += (rr[1][c] + rr[3][c]) * k1;
+            sum += (rr[0][c] + rr[4][c]) * k2;
+            sg |= (uint32_t)((int)dsign(yv.v[c], sum) + 1) << (10 * c);
         }
         if (owner)
         {
@@ -820,6 +970,19 @@ __global__ __launch_bounds__(64 * SRX_A_WPB, SRX_A_WAVES) void k_forward_sign_s4
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             mc[r] = mn[r];
+        yv = yn;
+        if (more)
+        {
+            // rows 4y+3+My .. 4y+6+My join the window; they start kFwdSpan rows below its first row
+            int slot_first = s + kFwdSpan;
+            slot_first = slot_first >= kFwdRing ? slot_first - kFwdRing : slot_first;
+            batch_put(slot_first, sv);
+            if (!early)
+                for (int item = tid; item < 4 * kItemsPerRow; item += nthreads)
+                    stage_piece(item, 4 * y + 3 + kFwdMy, slot_first);
+        }
+        s = s + 4 >= kFwdRing ? s + 4 - kFwdRing : s + 4;
+        __syncthreads();
     }
 }
 
@@ -1230,13 +1393,19 @@ int launch_relative_motions(const PtrList& fwd, const MutPtrList& rel, int n, in
     return check_launch("relative_motions");
 }
 
-static int launch_group_maps(uint32_t* dec_bwd, size_t hr_px, int hr_cols, hipStream_t st)
+static int launch_group_maps(const int16_t* bwd_map, uint32_t* dec_bwd, size_t hr_px, int hr_cols, hipStream_t st)
 {
     const int bs = 256;
     const size_t entries = hr_px / 4; // scale 4: every row is a whole number of groups
-    hipLaunchKernelGGL(k_group_maps, dim3((unsigned)((entries + bs - 1) / bs)), dim3(bs), 0, st, dec_bwd,
-                       (int)(hr_px / hr_cols), hr_cols);
-    return check_launch("group_maps");
+    hipLaunchKernelGGL(k_group_maps, dim3((unsigned)((entries + bs - 1) / bs)), dim3(bs), 0, st,
+                       (const short2*)bwd_map, dec_bwd, (int)(hr_px / hr_cols), hr_cols);
+    if (int rc = check_launch("group_maps"))
+        return rc;
+    const int hr_rows = (int)(hr_px / hr_cols), w = hr_cols / 4, h = hr_rows / 4;
+    const int strips_x = (w + kFwdStrip - 1) / kFwdStrip;
+    hipLaunchKernelGGL(k_group_flags, dim3(strips_x, h), dim3(64), 0, st, dec_bwd, (uint8_t*)(dec_bwd + hr_px / 2),
+                       hr_rows, hr_cols, strips_x);
+    return check_launch("group_flags");
 }
 
 int launch_build_maps(const float* rel, int rows, int cols, int scale, const CubicTables& t, int16_t* fwd_map,
@@ -1249,21 +1418,24 @@ int launch_build_maps(const float* rel, int rows, int cols, int scale, const Cub
     }
     const dim3 b(64, 4);
     hipLaunchKernelGGL(k_build_maps, grid2d(cols * scale, rows * scale, b), b, 0, st, rel, rows, cols, scale, t,
-                       (short2*)fwd_map, (short2*)bwd_map, dec_fwd, dec_bwd);
+                       (short2*)fwd_map, (short2*)bwd_map, dec_fwd);
     if (int rc = check_launch("build_maps"))
         return rc;
-    return dec_bwd ? launch_group_maps(dec_bwd, (size_t)rows * scale * cols * scale, cols * scale, st) : 0;
+    return dec_bwd ? launch_group_maps(bwd_map, dec_bwd, (size_t)rows * scale * cols * scale, cols * scale, st) : 0;
 }
 
 int launch_decode_maps(const int16_t* fwd_map, const int16_t* bwd_map, int hr_rows, int hr_cols, uint32_t* dec_fwd,
                        uint32_t* dec_bwd, hipStream_t st)
 {
     const dim3 b(64, 4);
-    hipLaunchKernelGGL(k_decode_maps, grid2d(hr_cols, hr_rows, b), b, 0, st, (const short2*)fwd_map,
-                       (const short2*)bwd_map, hr_rows, hr_cols, dec_fwd, dec_bwd);
-    if (int rc = check_launch("decode_maps"))
-        return rc;
-    return dec_bwd ? launch_group_maps(dec_bwd, (size_t)hr_rows * hr_cols, hr_cols, st) : 0;
+    if (dec_fwd)
+    {
+        hipLaunchKernelGGL(k_decode_maps, grid2d(hr_cols, hr_rows, b), b, 0, st, (const short2*)fwd_map, hr_rows,
+                           hr_cols, dec_fwd);
+        if (int rc = check_launch("decode_maps"))
+            return rc;
+    }
+    return dec_bwd ? launch_group_maps(bwd_map, dec_bwd, (size_t)hr_rows * hr_cols, hr_cols, st) : 0;
 }
 
 int launch_resize_cubic(const float* src, int srows, int scols, int ch, const CubicTables& t, float* dst, int drows,
@@ -1333,7 +1505,7 @@ int launch_sign_unpair(const uint32_t* pairs, uint32_t* plain, int lr_rows, int 
 bool forward_fast_eligible(int hr_rows, int hr_cols, int ch, int scale, const GaussK& g)
 {
     return scale == 4 && g.n == 5 && (ch == 1 || ch == 3) && hr_rows % 4 == 0 && hr_cols % 4 == 0 &&
-           (size_t)hr_rows * hr_cols < (1u << 30);
+           hr_rows <= kGrpMaxDim && hr_cols <= kGrpMaxDim;
 }
 
 int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const PtrList& raw_bwd,
@@ -1350,17 +1522,43 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
         const int w = hr_cols / 4, h = hr_rows / 4;
         const size_t ps = plane_stride_for((size_t)hr_rows * hr_cols);
         const int strips_x = (w + kFwdStrip - 1) / kFwdStrip;
-        const int row_groups = (h + kFwdRowsPerWave - 1) / kFwdRowsPerWave;
-        const unsigned n_items = (unsigned)strips_x * row_groups * K; // one wave each
-        const unsigned n_blocks = (n_items + SRX_A_WPB - 1) / SRX_A_WPB;
-        const dim3 gr(xcd_grid(n_blocks)), b(64 * SRX_A_WPB);
+        // one wave per window frame, at most kFwdMaxWaves frames per block (more frames: more passes)
+        const int passes = (K + kFwdMaxWaves - 1) / kFwdMaxWaves;
+        const int waves = (K + passes - 1) / passes;
+        // cut the rows so that one round of resident blocks covers the image
+        static int cus = 0;
+        if (cus == 0)
+        {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+                return check_launch("forward_sign_lds (device query)");
+            cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        const int blocks_per_cu = forward_lds_bytes(ch) * 2 <= 160 * 1024 ? 2 : 1;
+        const int slots = std::max(1, blocks_per_cu * cus / (strips_x * passes));
+        const int rows_per_tile = std::max(4, (h + slots - 1) / slots);
+        const int row_groups = (h + rows_per_tile - 1) / rows_per_tile;
+        const unsigned n_tiles = (unsigned)strips_x * row_groups;
+        const dim3 gr(xcd_grid(n_tiles), passes), b(64 * waves);
+        const size_t lds = forward_lds_bytes(ch);
+        static bool lds_set = false;
+        if (!lds_set)
+        {
+            if (hipFuncSetAttribute((const void*)k_forward_sign_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)forward_lds_bytes(1)) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_forward_sign_lds<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)forward_lds_bytes(3)) != hipSuccess)
+                return check_launch("forward_sign_lds (LDS size)");
+            lds_set = true;
+        }
         if (ch == 1)
-            hipLaunchKernelGGL(k_forward_sign_s4<1>, gr, b, 0, st, X, hr_rows, hr_cols, ps, *dec_bwd, y, signs, K, g,
-                               strips_x, n_items, n_blocks);
+            hipLaunchKernelGGL(k_forward_sign_lds<1>, gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd, y, signs,
+                               K, g, strips_x, rows_per_tile, n_tiles);
         else
-            hipLaunchKernelGGL(k_forward_sign_s4<3>, gr, b, 0, st, X, hr_rows, hr_cols, ps, *dec_bwd, y, signs, K, g,
-                               strips_x, n_items, n_blocks);
-        return check_launch("forward_sign_s4");
+            hipLaunchKernelGGL(k_forward_sign_lds<3>, gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd, y, signs,
+                               K, g, strips_x, rows_per_tile, n_tiles);
+        return check_launch("forward_sign_lds");
     }
     const dim3 b(64, 4);
     const dim3 gr = grid2d(hr_cols / scale, hr_rows / scale, b, K);

@@ -35,7 +35,10 @@ class Camera:
 
 
 def camera_path(n_frames: int, seed: int = 1234, max_shift: float = 1.7, max_rot: float = 0.002,
-                max_zoom: float = 0.002) -> List[Camera]:
+                max_zoom: float = 0.002, rot_growth: bool = False) -> List[Camera]:
+    """Random-walk translation (steps of at most max_shift HR pixels per axis) with a small rotation and zoom
+    per frame.  The rotation is stationary: every frame's angle is uniform in +-max_rot.  rot_growth=True lets
+    the amplitude grow with sqrt(frame index), the model the committed golden files were generated with."""
     g = torch.Generator().manual_seed(seed)
     cams = []
     tx = ty = 0.0
@@ -43,7 +46,7 @@ def camera_path(n_frames: int, seed: int = 1234, max_shift: float = 1.7, max_rot
         r = torch.rand(4, generator=g).tolist()
         tx += (r[0] * 2 - 1) * max_shift
         ty += (r[1] * 2 - 1) * max_shift
-        ang = (r[2] * 2 - 1) * max_rot * (t + 1) ** 0.5
+        ang = (r[2] * 2 - 1) * max_rot * ((t + 1) ** 0.5 if rot_growth else 1.0)
         z = 1.0 + (r[3] * 2 - 1) * max_zoom
         c, s = math.cos(ang) * z, math.sin(ang) * z
         cams.append(Camera(c, -s, s, c, tx, ty))
@@ -139,11 +142,12 @@ def true_forward_flow(cam0: Camera, cam1: Camera, lr_rows: int, lr_cols: int, sc
 
 def make_sequence(n_frames: int, lr_rows: int, lr_cols: int, channels: int, scale: int, seed: int = 1234,
                   device="cpu", noise: bool = False, keep_gold: bool = False, max_shift: float = 1.7,
-                  max_rot: float = 0.002) -> Tuple[List[torch.Tensor], List[torch.Tensor], List[torch.Tensor]]:
+                  max_rot: float = 0.002,
+                  rot_growth: bool = False) -> Tuple[List[torch.Tensor], List[torch.Tensor], List[torch.Tensor]]:
     """Returns (lr_frames uint8, true forward flows (n-1), gold HR frames uint8 or []).
 
     max_shift bounds the camera translation per frame (LR pixels), max_rot scales its rotation (radians)."""
-    cams = camera_path(n_frames, seed, max_shift=max_shift, max_rot=max_rot)
+    cams = camera_path(n_frames, seed, max_shift=max_shift, max_rot=max_rot, rot_growth=rot_growth)
     gen = torch.Generator().manual_seed(seed + 1)
     lr, gold = [], []
     for t in range(n_frames):

@@ -21,7 +21,7 @@ from superresolution_amd import synth  # noqa: E402
 
 def solve_case(name, K, rows, cols, ch, base, seed, **kw):
     p = oracle.BtvParams(**kw)
-    lr, flows, _ = synth.make_sequence(K, rows, cols, ch, p.scale, seed=seed)
+    lr, flows, _ = synth.make_sequence(K, rows, cols, ch, p.scale, seed=seed, rot_growth=True)
     lr = [f.numpy() for f in lr]
     fl = [f.numpy() for f in flows]
     out, full = oracle.btvl1_process([f.astype(np.float32) for f in lr], fl, base, p, return_full=True)
@@ -32,7 +32,7 @@ def solve_case(name, K, rows, cols, ch, base, seed, **kw):
 
 
 def stream_case(name, n, rows, cols, ch, r, T, seed):
-    lr, flows, _ = synth.make_sequence(n, rows, cols, ch, 4, seed=seed)
+    lr, flows, _ = synth.make_sequence(n, rows, cols, ch, 4, seed=seed, rot_growth=True)
     lr = [f.numpy() for f in lr]
     fl = [f.numpy() for f in flows]
     it = iter(fl)
