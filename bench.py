@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--iterations", type=int, default=180)
     ap.add_argument("--flow", choices=["synthetic", "tvl1"], default="tvl1",
                     help="motion stage: exact synthetic motion resident in HBM, or the built-in TV-L1 flow")
+    ap.add_argument("--no-read-ahead", action="store_true",
+                    help="read each frame in the call that needs it, as the reference does (default: the next "
+                         "frame is read one call early and its TV-L1 flow runs beside the current solve)")
     ap.add_argument("--host-io", action="store_true",
                     help="hand over host frames and take host output (the PCIe-inclusive rate; never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -144,7 +147,8 @@ def main():
     # Calls: one set-up call (ring warm-up: 2r+2 reads), then W warm-up and K timed steady-state steps with one
     # read, one flow and one solve each.  The solve of a call runs r+1 frames ahead of the output it returns, so
     # a span of W + K + r + 2 owned frames keeps every timed solve inside the span with a full window.
-    n_own = args.warmup + args.steps + r + 2
+    read_ahead = args.flow == "tvl1" and not args.no_read_ahead
+    n_own = args.warmup + args.steps + r + 2 + (1 if read_ahead else 0)  # read-ahead pulls one frame more
     total = n_own * world
     a = rank * n_own
     cams = synth.camera_path(total + 2 * r + 2, seed=1234)
@@ -175,6 +179,7 @@ def main():
     sr.set("iterations", args.iterations)
     sr.set("temporalAreaRadius", r)
     sr.set("outputMemory", L.SRX_MEM_HOST if args.host_io else L.SRX_MEM_DEVICE)
+    sr.set("readAhead", 1 if read_ahead else 0)
     if args.flow == "tvl1":
         sr.setOpticalFlow(api.DualTVL1())
     else:
@@ -262,6 +267,7 @@ def main():
                             + ("built-in TV-L1 flow" if args.flow == "tvl1" else "exact synthetic flow resident in HBM"),
                 "frames_per_gpu": args.steps,
                 "io": "host frames in, host frames out (PCIe inclusive)" if args.host_io else "frames resident in HBM",
+                "read_ahead": read_ahead,
                 "partition": "contiguous span of output frames per GPU, halo of r LR frames swapped point to point",
                 "halo_exchange_ms": round(halo_ms, 3),
                 "step_ms": [round(v, 2) for v in step_ms],

@@ -97,6 +97,16 @@ struct srx_handle
     PinnedBuffer dst_host;
     int outputMemory = SRX_MEM_HOST;
 
+    // readAhead: the frame of the NEXT call is read, and its flow computed on a second stream,
+    // while the solve of this call runs.  Same results, one frame more read from the source.
+    int readAhead = 0;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t prev_ready = nullptr;
+    bool look_valid = false, look_end = false;
+    std::vector<uint8_t> look_host;
+    DeviceBuffer look_dev, look_flow;
+    srx_image look_hdr{};
+
     int out_first = 0, out_last = -1; // first > last: unrestricted
     bool trace = false;
     std::vector<Event> events;
@@ -118,7 +128,8 @@ struct srx_handle
     }
 
     int to_float(const srx_image& im, float* dst);
-    int add_new_frame(const srx_image& frame);
+    int add_new_frame(const srx_image& frame, bool flow_ready = false);
+    int read_ahead();
     int process_frame(int idx);
     int init_impl();
     int process_impl(srx_image* out, bool* produced);
@@ -173,7 +184,8 @@ int srx_handle::calc_flow(const srx_image& f0, const srx_image& f1, float* dst)
 }
 
 // BTV_L1::addNewFrame, lib/src/btv_l1.cpp:511-525
-int srx_handle::add_new_frame(const srx_image& frame)
+// With flow_ready the motion prevFrame -> frame is already in look_flow (read_ahead).
+int srx_handle::add_new_frame(const srx_image& frame, bool flow_ready)
 {
     if (int rc = check_image(frame, "frame source"))
         return rc;
@@ -199,7 +211,12 @@ int srx_handle::add_new_frame(const srx_image& frame)
         if (int rc = to_float(frame, f.as<float>()))
             return rc;
     }
-    if (storePos > 0)
+    if (storePos > 0 && flow_ready)
+    {
+        if (!dry)
+            std::swap(motions[slot(storePos - 1)], look_flow);
+    }
+    else if (storePos > 0)
     {
         log(SRX_EV_FLOW, storePos - 1);
         float* dst = nullptr;
@@ -234,6 +251,63 @@ int srx_handle::add_new_frame(const srx_image& frame)
             return rc;
         prev_hdr.data = prev_dev.get();
     }
+    return SRX_OK;
+}
+
+// Reads the next call's frame now and computes its flow on the second stream; the solve enqueued
+// on the main stream runs meanwhile (the flow's many small launches fit beside it).
+int srx_handle::read_ahead()
+{
+    srx_image f{};
+    const int got = next(user, &f);
+    log(SRX_EV_READ, got ? 1 : 0);
+    if (!got)
+    {
+        look_end = true;
+        return SRX_OK;
+    }
+    if (int rc = check_image(f, "frame source"))
+        return rc;
+    if (f.rows != rows || f.cols != cols || f.channels != ch || f.depth != depth)
+    {
+        set_error("frame size or type changed within the stream");
+        return SRX_ERR_INVALID;
+    }
+    const size_t rowbytes = (size_t)cols * ch * elem_size(depth);
+    look_hdr = f;
+    look_hdr.step = rowbytes;
+    if (!dry && !stream2)
+    {
+        SRX_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+        SRX_HIP(hipEventCreateWithFlags(&prev_ready, hipEventDisableTiming));
+    }
+    if (f.mem == SRX_MEM_HOST)
+    {
+        look_host.resize(rowbytes * rows);
+        const size_t step = f.step ? f.step : rowbytes;
+        for (int y = 0; y < rows; ++y)
+            std::memcpy(look_host.data() + (size_t)y * rowbytes, (const uint8_t*)f.data + (size_t)y * step, rowbytes);
+        look_hdr.data = look_host.data();
+    }
+    else if (!dry)
+    {
+        if (int rc = look_dev.reserve(rowbytes * rows))
+            return rc;
+        if (int rc = copy_to_device(f, look_dev.get(), stream2))
+            return rc;
+        look_hdr.data = look_dev.get();
+    }
+    log(SRX_EV_FLOW, storePos);
+    if (!dry)
+    {
+        if (int rc = look_flow.reserve((size_t)rows * cols * 2 * sizeof(float)))
+            return rc;
+        SRX_HIP(hipStreamWaitEvent(stream2, prev_ready, 0)); // prevFrame was written on the main stream
+        if (int rc = tvl1.calc_images(prev_hdr, look_hdr, flow_params, look_flow.as<float>(), nullptr, stream2))
+            return rc;
+        SRX_HIP(hipStreamSynchronize(stream2));
+    }
+    look_valid = true;
     return SRX_OK;
 }
 
@@ -307,15 +381,37 @@ int srx_handle::process_impl(srx_image* out, bool* produced)
 {
     *produced = false;
     srx_image frame{};
-    const int got = next(user, &frame);
-    log(SRX_EV_READ, got ? 1 : 0);
+    int got = 0;
+    const bool ahead = look_valid;
+    if (ahead)
+        frame = look_hdr, got = 1, look_valid = false;
+    else if (!look_end)
+    {
+        got = next(user, &frame);
+        log(SRX_EV_READ, got ? 1 : 0);
+    }
     if (got)
-        if (int rc = add_new_frame(frame))
+        if (int rc = add_new_frame(frame, ahead))
             return rc;
+    const bool look = readAhead && flow_kind == SRX_FLOW_TVL1 && got && !look_end;
+    if (look && !dry && stream2)
+        SRX_HIP(hipEventRecord(prev_ready, stream));
     if (procPos < storePos)
     {
         ++procPos;
         if (int rc = process_frame(procPos))
+            return rc;
+    }
+    if (look)
+    {
+        if (!dry && !stream2)
+        {
+            SRX_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+            SRX_HIP(hipEventCreateWithFlags(&prev_ready, hipEventDisableTiming));
+            // first use: the copy of prevFrame is somewhere in the work already enqueued
+            SRX_HIP(hipEventRecord(prev_ready, stream));
+        }
+        if (int rc = read_ahead())
             return rc;
     }
     if (outPos < storePos)
@@ -397,11 +493,18 @@ SRX_API void srx_destroy(srx_handle* h)
         (void)hipSetDevice(h->device);
         (void)hipStreamSynchronize(h->stream);
     }
-    hipStream_t st = h->stream;
+    hipStream_t st = h->stream, st2 = h->stream2;
+    hipEvent_t ev = h->prev_ready;
+    if (st2)
+        (void)hipStreamSynchronize(st2);
     const bool dry = h->dry;
     delete h;
     if (!dry && st)
         (void)hipStreamDestroy(st);
+    if (st2)
+        (void)hipStreamDestroy(st2);
+    if (ev)
+        (void)hipEventDestroy(ev);
 }
 
 // ---- parameters -----------------------------------------------------------
@@ -426,6 +529,8 @@ static int* int_param(srx_handle* h, const std::string& n)
         return &h->p.temporalAreaRadius;
     if (n == "outputMemory")
         return &h->outputMemory;
+    if (n == "readAhead")
+        return &h->readAhead;
     return nullptr;
 }
 static double* double_param(srx_handle* h, const std::string& n)
@@ -469,6 +574,11 @@ SRX_API int srx_set_int(srx_handle* h, const char* name, int value)
                 set_error("outputMemory must be SRX_MEM_HOST or SRX_MEM_DEVICE");
                 return SRX_ERR_INVALID;
             }
+            return SRX_OK;
+        }
+        if (n == "readAhead")
+        {
+            *p = value != 0;
             return SRX_OK;
         }
         if (int rc = validate_params(h->p))
@@ -606,6 +716,7 @@ SRX_API int srx_set_input(srx_handle* h, srx_next_frame_fn next, srx_reset_fn re
     h->reset = reset;
     h->user = user;
     h->firstCall = true;
+    h->look_valid = h->look_end = false;
     return SRX_OK;
 }
 
@@ -615,6 +726,7 @@ SRX_API int srx_reset(srx_handle* h)
     if (h->reset)
         h->reset(h->user);
     h->firstCall = true;
+    h->look_valid = h->look_end = false;
     return SRX_OK;
 }
 

@@ -127,3 +127,48 @@ def test_streaming_with_builtin_flow_matches_oracle():
         a, b = o.nextFrame(), sr.nextFrame()
         assert np.array_equal(a, np.asarray(b))
     assert o.nextFrame() is None and sr.nextFrame() is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mem", ["host", "device"])
+def test_read_ahead_gives_the_same_frames(mem):
+    """readAhead computes the next pair's flow beside the current solve: same outputs, frame for frame, the same
+    end of stream, and a reset() starts over."""
+    import torch
+    from oracle import stream as ostream
+    from superresolution_amd import api, _lib as L
+
+    n, r, T = 9, 2, 4
+    lr, _, _ = synth.make_sequence(n, 24, 32, 3, 4, seed=33)
+    frames = [f.numpy() for f in lr] if mem == "host" else [f.cuda() for f in lr]
+
+    def run(read_ahead, twice=False):
+        sr = api.BTV_L1()
+        sr.set("iterations", T)
+        sr.set("temporalAreaRadius", r)
+        sr.set("readAhead", read_ahead)
+        assert sr.getInt("readAhead") == read_ahead
+        sr.setOpticalFlow(api.DualTVL1())
+        for k, v in dict(nscales=2, warps=2, iterations=20).items():
+            sr.flowSet(k, v)
+        if mem == "device":
+            sr.set("outputMemory", L.SRX_MEM_DEVICE)
+        sr.setFrameSource(ostream.ListFrameSource(frames))
+        outs = []
+        for _ in range(2 if twice else 1):
+            outs.append([])
+            while True:
+                f = sr.nextFrame()
+                if f is None:
+                    break
+                outs[-1].append(f.cpu().numpy().copy() if mem == "device" else np.array(f, copy=True))
+            assert sr.nextFrame() is None
+            sr.reset()
+        return outs
+
+    ref = run(0)[0]
+    assert len(ref) == n
+    for got in run(1, twice=True):
+        assert len(got) == n
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b)
