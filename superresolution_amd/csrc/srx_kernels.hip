@@ -1012,6 +1012,14 @@ __device__ __forceinline__ float fold_zero(float x)
 {
     return x + 0.0f;
 }
+// a * b + c on the low 24 bits of a and b: one v_mad_u32_u24 (the compiler prefers two multiplies and a
+// three-way add for a pair of these)
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ int sign_of_difference(float t)
 {
     int s;
@@ -1234,13 +1242,12 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
         for (int p = 0; p < PXT; ++p)
             accv[p] = 0;
         int pending = 0;
-        for (int k = 0; k < K; ++k)
-        {
-            uint4 nxt = cur;
+        // one window frame: gathers through the entries in `now` while the next frame's entries arrive in `next`
+        auto frame = [&](int k, const uint4& now, uint4& next) {
             if (k + 1 < K)
-                nxt = stream_load((const uint4*)((const uint32_t*)dec_fwd.p[k + 1] + pix));
+                next = stream_load((const uint4*)((const uint32_t*)dec_fwd.p[k + 1] + pix));
             const char* sg = (const char*)signs.p[k];
-            const uint32_t ev[PXT] = {cur.x, cur.y, cur.z, cur.w};
+            const uint32_t ev[PXT] = {now.x, now.y, now.z, now.w};
             uint4_a8 qs[PXT];
 #pragma unroll
             for (int p = 0; p < PXT; ++p)
@@ -1254,10 +1261,10 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
                 const char* le = lutb + ((e >> (kFwdLutShift - 4)) & 0x1F0u);
                 const uint4 wq = *(const uint4*)le;
                 uint32_t v = accv[p];
-                v += __umul24(q.x, wq.x);
-                v += __umul24(q.y, wq.y);
-                v += __umul24(q.z, wq.z);
-                v += __umul24(q.w, wq.w);
+                v = mad_u24(q.x, wq.x, v);
+                v = mad_u24(q.y, wq.y, v);
+                v = mad_u24(q.z, wq.z, v);
+                v = mad_u24(q.w, wq.w, v);
                 accv[p] = v;
                 bias[p] += *(const uint32_t*)(le + kFwdLutSize * 16);
             }
@@ -1273,8 +1280,17 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
                 }
                 pending = 0;
             }
-            cur = nxt;
+        };
+        // two frames per trip, the two entry registers swapping roles (no copies)
+        uint4 alt = cur;
+        int k = 0;
+        for (; k + 1 < K; k += 2)
+        {
+            frame(k, cur, alt);
+            frame(k + 1, alt, cur);
         }
+        if (k < K)
+            frame(k, cur, alt);
     }
     // ---- update
     if (!live)
