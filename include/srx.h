@@ -94,7 +94,10 @@ SRX_API const char* srx_last_error(void);
 /* names and types as registered at lib/src/super_resolution.cpp:83-93:
  * scale, iterations, btvKernelSize, blurKernelSize, temporalAreaRadius (int);
  * tau, lambda, alpha, blurSigma (double).  Extra int names of this library:
- * outputMemory (SRX_MEM_*; default host), traceEvents (0/1), kernelTiming (0/1). */
+ * outputMemory (SRX_MEM_*; default host), traceEvents (0/1), kernelTiming (0/1),
+ * readAhead (0/1, default 0; built-in flow only): srx_next_frame pulls the frame of the NEXT call from the
+ * source while the current solve runs and computes its flow on a second stream.  Same frames out; the
+ * source is read one frame earlier than BTV_L1::processImpl (lib/src/btv_l1.cpp:490-509) would. */
 SRX_API int srx_set_int(srx_handle* h, const char* name, int value);
 SRX_API int srx_set_double(srx_handle* h, const char* name, double value);
 SRX_API int srx_get_int(srx_handle* h, const char* name, int* value);

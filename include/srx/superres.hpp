@@ -284,6 +284,7 @@ class BTV_L1 : public SuperResolution
     void nextFrame(Mat& frame) { frame = nextFrame(); } // upstream spelling
     void setOutputRange(int first, int last) { check(srx_set_output_range(h_, first, last)); }
     void setOutputOnDevice(bool on) { set("outputMemory", on ? SRX_MEM_DEVICE : SRX_MEM_HOST); }
+    void setReadAhead(bool on) { set("readAhead", on ? 1 : 0); } // next frame's flow beside the current solve
 
     // ---- BTV_L1_Base::process (lib/src/btv_l1.cpp:297-355); dst is allocated (host) when empty
     void process(const std::vector<Mat>& src, Mat& dst, int baseIdx = 0) { process_impl(src, dst, nullptr, baseIdx); }

@@ -19,7 +19,7 @@ import numpy as np
 from . import _lib as L
 
 _INT_PARAMS = ("scale", "iterations", "btvKernelSize", "blurKernelSize", "temporalAreaRadius", "outputMemory",
-               "traceEvents", "kernelTiming")
+               "traceEvents", "kernelTiming", "readAhead")
 _DOUBLE_PARAMS = ("tau", "lambda", "alpha", "blurSigma")
 
 
