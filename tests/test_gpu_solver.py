@@ -64,6 +64,10 @@ CASES = [
     (2, 16, 20, 1, 1, dict(iterations=6, lambda_=0.0)),
     (1, 16, 20, 3, 0, dict(iterations=6)),
     (17, 14, 18, 3, 8, dict(iterations=4, scale=2)),
+    # more window frames than one block of the scale-4 forward kernel takes (two passes over the tile),
+    # and a strip boundary (more than 63 LR columns)
+    (11, 12, 70, 3, 5, dict(iterations=3)),
+    (13, 10, 16, 1, 0, dict(iterations=3)),
 ]
 
 

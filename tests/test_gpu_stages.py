@@ -137,6 +137,36 @@ def test_forward_sign(ops, rng, rows, cols, ch, scale, n, sigma):
     assert np.array_equal(got, ops.pack_signs(ref.reshape(rows, cols, ch)))
 
 
+@pytest.mark.parametrize("rows,cols,ch,kind", [(40, 70, 3, "large"), (40, 70, 1, "large"), (36, 130, 3, "jitter"),
+                                               (24, 64, 1, "jitter"), (33, 65, 3, "outside"), (20, 127, 3, "wild")])
+def test_forward_sign_beyond_the_lds_window(ops, rng, rows, cols, ch, kind):
+    """Motions the specialised forward kernel cannot serve from its LDS window (sources more than 15 rows / 16
+    columns away, neighbouring pixels whose sources are far apart, sources outside every border): the values
+    must not depend on which path fetched them."""
+    scale = 4
+    H, W = rows * scale, cols * scale
+    X = (rng.random((H, W, ch)) * 255).astype(np.float32)
+    if kind == "large":      # smooth, up to ~40 HR pixels
+        rel = smooth_motion(rng, rows, cols, amp=5.0)
+    elif kind == "jitter":   # neighbouring LR pixels move independently: groups that are not runs, far groups
+        rel = smooth_motion(rng, rows, cols, amp=1.0) + rng.standard_normal((rows, cols, 2)).astype(np.float32) * 3.0
+    elif kind == "outside":  # the whole frame shifted so that bands at two borders leave the image
+        rel = np.zeros((rows, cols, 2), np.float32)
+        rel[..., 0], rel[..., 1] = 3.3, -2.6
+    else:                    # int16 saturation of the map and everything in between
+        rel = rng.standard_normal((rows, cols, 2)).astype(np.float32) * 40.0
+        rel[3, 5] = (20000.0, -20000.0)
+    hr = oracle.upscale_motion(rel, scale)
+    _, bwd = oracle.build_motion_maps(hr)
+    gk = oracle.gaussian_kernel(5, 0.0)
+    proj = oracle.resize_nearest(oracle.sep_filter(oracle.remap_nearest(X, bwd), gk), rows, cols)
+    y = proj + rng.integers(-1, 2, proj.shape).astype(np.float32)
+    ref = _forward_ref(X, bwd, y, scale, gk)
+    _, bwd_map = ops.build_maps(dev(rel), scale)
+    got = host(ops.forward_sign(dev(X), bwd_map, dev(y), scale, gk))
+    assert np.array_equal(got, ops.pack_signs(ref.reshape(rows, cols, ch)))
+
+
 def _backproject_ref(X, signs, fwd_floats, scale, gk, B, w, tau, lam):
     diff = np.zeros_like(X)
     for s, f in zip(signs, fwd_floats):
