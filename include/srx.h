@@ -35,10 +35,13 @@ enum
     SRX_ERR_FLOW = 5     /* the optical-flow plug-in failed             */
 };
 
-/* depth codes are OpenCV's CV_8U / CV_32F */
+/* depth codes are OpenCV's CV_8U / CV_16U / CV_32F.  Frames convert to float unscaled
+ * (frame.convertTo(CV_32F), lib/src/btv_l1.cpp:519); the flow stage rescales to 8 bit
+ * (convertToType, lib/src/input_array_utility.cpp:90-103). */
 enum
 {
     SRX_8U = 0,
+    SRX_16U = 2,
     SRX_32F = 5
 };
 enum

@@ -42,6 +42,8 @@ inline void check(int rc)
 }
 
 // Minimal stand-in for cv::Mat: a ref-counted or borrowed dense image in host or device memory.
+inline size_t elemSize1(int depth) { return depth == SRX_8U ? 1 : (depth == SRX_16U ? 2 : 4); }
+
 class Mat
 {
   public:
@@ -56,7 +58,7 @@ class Mat
 
     void create(int rows, int cols, int channels, int depth)
     {
-        const size_t bytes = (size_t)rows * cols * channels * (depth == SRX_8U ? 1 : 4);
+        const size_t bytes = (size_t)rows * cols * channels * elemSize1(depth);
         if (!own_ || own_->size() != bytes || own_.use_count() > 1)
             own_ = std::make_shared<std::vector<uint8_t>>(bytes);
         im_ = srx_image{own_->data(), rows, cols, channels, depth, 0, SRX_MEM_HOST};
@@ -68,7 +70,7 @@ class Mat
     int channels() const { return im_.channels; }
     int depth() const { return im_.depth; }
     bool onDevice() const { return im_.mem == SRX_MEM_DEVICE; }
-    size_t step() const { return im_.step ? im_.step : (size_t)im_.cols * im_.channels * (im_.depth == SRX_8U ? 1 : 4); }
+    size_t step() const { return im_.step ? im_.step : (size_t)im_.cols * im_.channels * elemSize1(im_.depth); }
     template <typename T> T* ptr(int y = 0) const { return (T*)((uint8_t*)im_.data + (size_t)y * step()); }
     const srx_image& view() const { return im_; }
     // borrowed view of a rectangle, like cv::Mat::operator()(Rect); shares this Mat's memory
@@ -80,7 +82,7 @@ class Mat
         m.own_ = own_;
         m.im_ = im_;
         m.im_.step = step();
-        m.im_.data = (uint8_t*)im_.data + (size_t)y * step() + (size_t)x * im_.channels * (im_.depth == SRX_8U ? 1 : 4);
+        m.im_.data = (uint8_t*)im_.data + (size_t)y * step() + (size_t)x * im_.channels * elemSize1(im_.depth);
         m.im_.rows = height, m.im_.cols = width;
         return m;
     }
@@ -91,7 +93,7 @@ class Mat
         if (empty() || onDevice())
             return m;
         m.create(im_.rows, im_.cols, im_.channels, im_.depth);
-        const size_t row = (size_t)im_.cols * im_.channels * (im_.depth == SRX_8U ? 1 : 4);
+        const size_t row = (size_t)im_.cols * im_.channels * elemSize1(im_.depth);
         for (int y = 0; y < im_.rows; ++y)
             std::memcpy(m.ptr<uint8_t>(y), ptr<uint8_t>(y), row);
         return m;

@@ -46,10 +46,10 @@ def to_gray(frame) -> np.ndarray:
     f = np.ascontiguousarray(frame)
     if f.ndim == 2:
         f = f[:, :, None]
-    assert f.dtype in (np.uint8, np.float32)
+    assert f.dtype in (np.uint8, np.uint16, np.float32)
+    kind = {np.dtype(np.uint8): 0, np.dtype(np.float32): 1, np.dtype(np.uint16): 2}[f.dtype]
     out = np.empty(f.shape[:2], np.float32)
-    _lib().orc_tvl1_to_gray(f.ctypes.data_as(C.c_void_p), f.shape[0], f.shape[1], f.shape[2],
-                            int(f.dtype == np.float32), _p(out))
+    _lib().orc_tvl1_to_gray(f.ctypes.data_as(C.c_void_p), f.shape[0], f.shape[1], f.shape[2], kind, _p(out))
     return out
 
 

@@ -61,16 +61,17 @@ static int clampi(int v, int lo, int hi)
 }
 
 /* frame (8U or 32F, 1/3/4 channels, dense) -> grey float in 0..255 */
-ORC_API void orc_tvl1_to_gray(const void* src, int rows, int cols, int ch, int is_float, float* dst)
+ORC_API void orc_tvl1_to_gray(const void* src, int rows, int cols, int ch, int kind, float* dst)
 {
     for (size_t i = 0; i < (size_t)rows * cols; ++i)
     {
         int c[4] = {0, 0, 0, 0};
         for (int k = 0; k < ch; ++k)
         {
-            if (is_float)
+            if (kind != 0) /* 1: float frames x 255; 2: 16-bit frames x 255/65535, scaled in float as cv::Mat::convertTo does */
             {
-                const float v = ((const float*)src)[i * ch + k] * 255.0f;
+                const float v = kind == 1 ? ((const float*)src)[i * ch + k] * 255.0f
+                                          : (float)((const unsigned short*)src)[i * ch + k] * (float)(255.0 / 65535.0);
                 float r = nearbyintf(v);
                 r = r < 0.f ? 0.f : (r > 255.f ? 255.f : r);
                 c[k] = (v != v) ? 0 : (int)r;

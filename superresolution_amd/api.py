@@ -42,20 +42,22 @@ def _describe(a, keep: list) -> L.SrxImage:
             im.depth = L.SRX_8U
         elif a.dtype == torch.float32:
             im.depth = L.SRX_32F
+        elif a.dtype in (torch.uint16, torch.int16):  # int16 storage is read as the 16-bit unsigned depth
+            im.depth = L.SRX_16U
         else:
-            raise TypeError("frames must be uint8 or float32")
+            raise TypeError("frames must be uint8, uint16 or float32")
         shape = tuple(a.shape)
         esz = a.element_size()
     else:
         a = np.asarray(a)
-        if a.dtype not in (np.uint8, np.float32):
-            raise TypeError("frames must be uint8 or float32")
+        if a.dtype not in (np.uint8, np.uint16, np.float32):
+            raise TypeError("frames must be uint8, uint16 or float32")
         if not a.flags["C_CONTIGUOUS"]:
             a = np.ascontiguousarray(a)
         keep.append(a)
         im.data = a.ctypes.data
         im.mem = L.SRX_MEM_HOST
-        im.depth = L.SRX_8U if a.dtype == np.uint8 else L.SRX_32F
+        im.depth = {np.dtype(np.uint8): L.SRX_8U, np.dtype(np.uint16): L.SRX_16U}.get(a.dtype, L.SRX_32F)
         shape = a.shape
         esz = a.itemsize
     if len(shape) == 2:
@@ -105,7 +107,7 @@ def _view(im: L.SrxImage):
     shape = (im.rows, im.cols, im.channels)
     n = im.rows * im.cols * im.channels
     if im.mem == L.SRX_MEM_HOST:
-        dt = np.uint8 if im.depth == L.SRX_8U else np.float32
+        dt = {L.SRX_8U: np.uint8, L.SRX_16U: np.uint16}.get(im.depth, np.float32)
         buf = (C.c_ubyte * (n * np.dtype(dt).itemsize)).from_address(im.data)
         a = np.frombuffer(buf, dtype=dt).reshape(shape)
         return a[:, :, 0] if im.channels == 1 else a
@@ -118,7 +120,7 @@ def _view(im: L.SrxImage):
     d = _Dev()
     d.__cuda_array_interface__ = {
         "shape": shape,
-        "typestr": "|u1" if im.depth == L.SRX_8U else "<f4",
+        "typestr": {L.SRX_8U: "|u1", L.SRX_16U: "<u2"}.get(im.depth, "<f4"),
         "data": (im.data, False),
         "version": 2,
     }
@@ -270,9 +272,10 @@ class BTV_L1:
             if f0.mem == L.SRX_MEM_DEVICE:
                 import torch
 
-                out = torch.empty(shape, dtype=torch.uint8 if f0.depth == L.SRX_8U else torch.float32, device="cuda")
+                out = torch.empty(shape, device="cuda",
+                                  dtype={L.SRX_8U: torch.uint8, L.SRX_16U: torch.uint16}.get(f0.depth, torch.float32))
             else:
-                out = np.empty(shape, np.uint8 if f0.depth == L.SRX_8U else np.float32)
+                out = np.empty(shape, {L.SRX_8U: np.uint8, L.SRX_16U: np.uint16}.get(f0.depth, np.float32))
         oh = _describe(out, keep)
         L.check(self._lib.srx_process(self._h, frames, n, motions, baseIdx, C.byref(oh)))
         if f0.channels == 1 and np.ndim(src[0]) == 2:

@@ -15,12 +15,12 @@ namespace
 
 size_t elem_size(int depth)
 {
-    return depth == SRX_8U ? 1 : 4;
+    return depth == SRX_8U ? 1 : (depth == SRX_16U ? 2 : 4);
 }
 
 int check_image(const srx_image& im, const char* what)
 {
-    if (!im.data || im.rows < 1 || im.cols < 1 || (im.depth != SRX_8U && im.depth != SRX_32F) || im.channels < 1 ||
+    if (!im.data || im.rows < 1 || im.cols < 1 || (im.depth != SRX_8U && im.depth != SRX_16U && im.depth != SRX_32F) || im.channels < 1 ||
         im.channels > 4 || (im.mem != SRX_MEM_HOST && im.mem != SRX_MEM_DEVICE))
     {
         set_error(std::string(what) + ": malformed image header");
@@ -142,10 +142,12 @@ int srx_handle::to_float(const srx_image& im, float* dst)
     const size_t count = (size_t)im.rows * im.cols * im.channels;
     if (im.depth == SRX_32F)
         return copy_to_device(im, dst, stream);
-    if (int rc = staging.reserve(count))
+    if (int rc = staging.reserve(count * elem_size(im.depth)))
         return rc;
     if (int rc = copy_to_device(im, staging.get(), stream))
         return rc;
+    if (im.depth == SRX_16U)
+        return launch_convert_16u_to_32f(staging.as<uint16_t>(), count, dst, stream);
     return launch_convert_8u_to_32f(staging.as<uint8_t>(), count, dst, stream);
 }
 
@@ -1356,7 +1358,7 @@ SRX_API int srx_k_crop_convert(const float* X, int rows, int cols, int ch, int b
                                void* stream)
 {
     if (!X || !dst || border < 0 || rows - 2 * border < 1 || cols - 2 * border < 1 ||
-        (depth != SRX_8U && depth != SRX_32F))
+        (depth != SRX_8U && depth != SRX_16U && depth != SRX_32F))
     {
         set_error("srx_k_crop_convert: bad arguments");
         return SRX_ERR_INVALID;

@@ -105,5 +105,6 @@ int launch_backproject_update(const float* X, float* X_out, int hr_rows, int hr_
 int launch_crop_convert(const float* X, int rows, int cols, int ch, int border, void* dst, int depth,
                         size_t plane_stride, hipStream_t st);
 int launch_convert_8u_to_32f(const uint8_t* src, size_t count, float* dst, hipStream_t st);
+int launch_convert_16u_to_32f(const uint16_t* src, size_t count, float* dst, hipStream_t st);
 
 } // namespace srx

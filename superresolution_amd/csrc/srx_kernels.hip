@@ -1344,7 +1344,8 @@ __global__ void k_sign_unpair(const uint2* __restrict__ pairs, uint32_t* __restr
 
 // ---------------------------------------------------------------------------
 // ps == 0: interleaved source; otherwise planar with plane stride ps
-template <int CH, bool TO8U>
+// DEPTH: 0 = 8-bit, 2 = 16-bit (convertTo: cvRound, half to even, then clamp; NaN -> 0), 5 = float
+template <int CH, int DEPTH>
 __global__ void k_crop_convert(const float* __restrict__ X, int rows, int cols, int border, void* __restrict__ dst,
                                size_t ps)
 {
@@ -1359,19 +1360,25 @@ __global__ void k_crop_convert(const float* __restrict__ X, int rows, int cols, 
     for (int c = 0; c < CH; ++c)
     {
         const float v = X[ps ? c * ps + pi : pi * CH + c];
-        if (TO8U)
+        if (DEPTH == 0)
         {
-            // convertTo(CV_8U): cvRound (half to even) then clamp; NaN -> 0
             float r = rintf(v);
             r = fminf(fmaxf(r, 0.0f), 255.0f);
             ((uint8_t*)dst)[o + c] = (uint8_t)(int)r;
+        }
+        else if (DEPTH == 2)
+        {
+            float r = rintf(v);
+            r = fminf(fmaxf(r, 0.0f), 65535.0f);
+            ((uint16_t*)dst)[o + c] = (uint16_t)(int)r;
         }
         else
             ((float*)dst)[o + c] = v;
     }
 }
 
-__global__ void k_convert_8u_to_32f(const uint8_t* __restrict__ src, size_t count, float* __restrict__ dst)
+template <typename T>
+__global__ void k_convert_to_32f(const T* __restrict__ src, size_t count, float* __restrict__ dst)
 {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < count)
@@ -1668,15 +1675,31 @@ int launch_crop_convert(const float* X, int rows, int cols, int ch, int border, 
 {
     const dim3 b(64, 4);
     const dim3 g = grid2d(cols - 2 * border, rows - 2 * border, b);
-    const bool u8 = depth == 0;
-    if (ch == 1 && u8)
-        hipLaunchKernelGGL((k_crop_convert<1, true>), g, b, 0, st, X, rows, cols, border, dst, plane_stride);
-    else if (ch == 1)
-        hipLaunchKernelGGL((k_crop_convert<1, false>), g, b, 0, st, X, rows, cols, border, dst, plane_stride);
-    else if (ch == 3 && u8)
-        hipLaunchKernelGGL((k_crop_convert<3, true>), g, b, 0, st, X, rows, cols, border, dst, plane_stride);
+    if (depth != 0 && depth != 2 && depth != 5)
+    {
+        set_error("crop_convert: depth must be 8U, 16U or 32F");
+        return 1;
+    }
+#define SRX_CROP(CHN, DEP) hipLaunchKernelGGL((k_crop_convert<CHN, DEP>), g, b, 0, st, X, rows, cols, border, dst, plane_stride)
+    if (ch == 1)
+    {
+        if (depth == 0)
+            SRX_CROP(1, 0);
+        else if (depth == 2)
+            SRX_CROP(1, 2);
+        else
+            SRX_CROP(1, 5);
+    }
     else if (ch == 3)
-        hipLaunchKernelGGL((k_crop_convert<3, false>), g, b, 0, st, X, rows, cols, border, dst, plane_stride);
+    {
+        if (depth == 0)
+            SRX_CROP(3, 0);
+        else if (depth == 2)
+            SRX_CROP(3, 2);
+        else
+            SRX_CROP(3, 5);
+    }
+#undef SRX_CROP
     else
     {
         set_error("crop_convert: channels must be 1 or 3");
@@ -1688,8 +1711,17 @@ int launch_crop_convert(const float* X, int rows, int cols, int ch, int border, 
 int launch_convert_8u_to_32f(const uint8_t* src, size_t count, float* dst, hipStream_t st)
 {
     const int bs = 256;
-    hipLaunchKernelGGL(k_convert_8u_to_32f, dim3((unsigned)((count + bs - 1) / bs)), dim3(bs), 0, st, src, count, dst);
+    hipLaunchKernelGGL(k_convert_to_32f<uint8_t>, dim3((unsigned)((count + bs - 1) / bs)), dim3(bs), 0, st, src, count,
+                       dst);
     return check_launch("convert_8u_to_32f");
+}
+
+int launch_convert_16u_to_32f(const uint16_t* src, size_t count, float* dst, hipStream_t st)
+{
+    const int bs = 256;
+    hipLaunchKernelGGL(k_convert_to_32f<uint16_t>, dim3((unsigned)((count + bs - 1) / bs)), dim3(bs), 0, st, src, count,
+                       dst);
+    return check_launch("convert_16u_to_32f");
 }
 
 } // namespace srx

@@ -124,7 +124,8 @@ __device__ __forceinline__ int reflect101(int p, int len)
 }
 
 // frame -> 8-bit grey as convertToType(frame, CV_8U, 1) does (lib/src/input_array_utility.cpp:77-124), as float
-__global__ void k_to_gray(const void* __restrict__ src, size_t count, int ch, int is_float, float* __restrict__ dst)
+// kind: 0 = 8-bit, 1 = float (x 255), 2 = 16-bit (x 255/65535 in float, as cv::Mat::convertTo scales)
+__global__ void k_to_gray(const void* __restrict__ src, size_t count, int ch, int kind, float* __restrict__ dst)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count)
@@ -132,9 +133,10 @@ __global__ void k_to_gray(const void* __restrict__ src, size_t count, int ch, in
     int c[4] = {0, 0, 0, 0};
     for (int k = 0; k < ch; ++k)
     {
-        if (is_float)
+        if (kind != 0)
         {
-            const float v = ((const float*)src)[i * ch + k] * 255.0f;
+            const float v = kind == 1 ? ((const float*)src)[i * ch + k] * 255.0f
+                                      : (float)((const uint16_t*)src)[i * ch + k] * (float)(255.0 / 65535.0);
             float r = rintf(v);
             r = r < 0.f ? 0.f : (r > 255.f ? 255.f : r);
             c[k] = (v != v) ? 0 : (int)r;
@@ -613,7 +615,7 @@ int Tvl1::calc_images(const srx_image& f0, const srx_image& f1, const Tvl1Params
         return SRX_ERR_INVALID;
     }
     const size_t px = (size_t)rows * cols;
-    const size_t esz = f0.depth == SRX_8U ? 1 : 4;
+    const size_t esz = f0.depth == SRX_8U ? 1 : (f0.depth == SRX_16U ? 2 : 4);
     const size_t rowbytes = (size_t)cols * ch * esz;
     if (int rc = m.lv[0].I0.reserve(px * sizeof(float)))
         return rc;
@@ -630,7 +632,7 @@ int Tvl1::calc_images(const srx_image& f0, const srx_image& f1, const Tvl1Params
         SRX_HIP(copy_pitched(raw[i]->get(), rowbytes, fr[i]->data, step, rowbytes, rows,
                              fr[i]->mem == SRX_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_to_gray, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, st, raw[i]->get(), px, ch,
-                           f0.depth == SRX_32F ? 1 : 0, gray[i]);
+                           f0.depth == SRX_32F ? 1 : (f0.depth == SRX_16U ? 2 : 0), gray[i]);
         SRX_LAUNCH_CHECK("to_gray");
     }
     return calc_gray(nullptr, nullptr, rows, cols, p, flow_uv, executed_iters, st);

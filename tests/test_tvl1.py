@@ -172,3 +172,47 @@ def test_read_ahead_gives_the_same_frames(mem):
         assert len(got) == n
         for a, b in zip(ref, got):
             assert np.array_equal(a, b)
+
+
+def test_gray_conversion_of_16_bit_frames_follows_convert_to():
+    """convertToType(frame, CV_8U, 1) on a 16-bit frame: value * (255/65535) in float, rounded half to even
+    (lib/src/input_array_utility.cpp:90-103)."""
+    v = np.array([[0, 128, 129, 257, 32767, 32896, 65535, 385]], np.uint16)
+    g = tvl1.to_gray(v)
+    exp = np.rint(v.astype(np.float32) * np.float32(255.0 / 65535.0))
+    assert np.array_equal(g, exp)
+    assert g[0, 0] == 0 and g[0, -2] == 255 and g[0, 3] == 1
+
+
+@pytest.mark.gpu
+def test_16_bit_frames_stream_and_batch():
+    """16-bit frames: unscaled conversion to float for the solver, rescaled to 8 bit for the flow; the stream
+    delivers 8-bit frames (btv_l1.cpp:504), process() delivers the depth it was given (btv_l1.cpp:456)."""
+    import oracle
+    from oracle import stream as ostream
+    from superresolution_amd import api
+
+    n, r, T = 5, 1, 4
+    lr, flows, _ = synth.make_sequence(n, 20, 28, 3, 4, seed=5)
+    lr16 = [(f.numpy().astype(np.uint16) * 3 + 7) for f in lr]     # values up to 772: beyond 8 bits
+    p = tvl1.Tvl1Params(nscales=2, warps=2, iterations=15)
+    o = ostream.BTV_L1(lambda f0, f1: tvl1.calc(f0, f1, p))
+    o.params = oracle.BtvParams(iterations=T)
+    o.temporalAreaRadius = r
+    o.setFrameSource(ostream.ListFrameSource(lr16))
+    sr = api.BTV_L1()
+    sr.set("iterations", T)
+    sr.set("temporalAreaRadius", r)
+    sr.setOpticalFlow(api.DualTVL1())
+    for k, v in dict(nscales=2, warps=2, iterations=15).items():
+        sr.flowSet(k, v)
+    sr.setFrameSource(ostream.ListFrameSource(lr16))
+    for _ in range(n):
+        a, b = o.nextFrame(), sr.nextFrame()
+        assert a.dtype == np.uint8 and np.array_equal(a, np.asarray(b))
+    # batch entry with given motions: result in the frames' depth
+    fl = [f.numpy() for f in flows]
+    ref = oracle.btvl1_process([f.astype(np.float32) for f in lr16], fl, 2, oracle.BtvParams(iterations=T))
+    got = sr.process(lr16, forwardMotions=fl, baseIdx=2)
+    assert got.dtype == np.uint16
+    assert np.array_equal(got, np.clip(np.rint(ref), 0, 65535).astype(np.uint16))
