@@ -271,9 +271,12 @@ static_assert(kFwdSpan + 4 <= kFwdRing && 2 * kFwdMy + 8 < kFwdRing,
               "rows staged during an LR row must not replace rows that row or the next one reads");
 static_assert(kFwdMx % 4 == 0, "staged columns start at a multiple of four");
 
-// One flag byte per (LR row, strip) of a frame's group map: 1 when every pixel the forward kernel
-// gathers for that row of that strip lies inside its LDS window and no group is "far", so that the
-// kernel may skip the checks.  One wave per (strip, LR row); lanes as in the forward kernel.
+// One flag byte per (LR row, strip) of a frame's group map: kRowInside when every pixel the forward
+// kernel gathers for that row of that strip lies inside its LDS window and no group is "far", so that
+// the kernel may skip the checks; kRowOutside when (nearly) no lane finds its pixels there, so that
+// the kernel goes to global memory right away.  One wave per (strip, LR row); lanes as in the forward
+// kernel.
+constexpr uint8_t kRowMixed = 0, kRowInside = 1, kRowOutside = 2;
 __global__ void k_group_flags(const uint32_t* __restrict__ grp, uint8_t* __restrict__ flags, int H, int W, int strips_x)
 {
     const int w = W >> 2, h = H >> 2;
@@ -282,7 +285,7 @@ __global__ void k_group_flags(const uint32_t* __restrict__ grp, uint8_t* __restr
     const int xl = min(max(x0 - 1 + lane, 0), w - 1);
     const int dc_lane = 4 * xl - (4 * (x0 - 1) - kFwdMx);
     const size_t entries = (size_t)h * w * 4;
-    bool ok = true;
+    bool ok = true, any = false;
     for (int r = 0; r < 4; ++r)
     {
         const size_t e = ((size_t)y * w + xl) * 4 + r;
@@ -290,17 +293,20 @@ __global__ void k_group_flags(const uint32_t* __restrict__ grp, uint8_t* __restr
         const int w1 = (int)grp[entries + e];
         const int dr = __builtin_amdgcn_sbfe((int)w0, 15, 15) + kFwdMy + 1 + r;
         const int dc = __builtin_amdgcn_sbfe((int)w0, 0, 15) + dc_lane;
-        ok = ok && (w0 & kGrpFar) == 0 && (unsigned)dr < (unsigned)kFwdSpan && (unsigned)dc < (unsigned)(4 * kFwdQuads);
+        bool in = (w0 & kGrpFar) == 0 && (unsigned)dr < (unsigned)kFwdSpan && (unsigned)dc < (unsigned)(4 * kFwdQuads);
         for (int j = 1; j < 4; ++j)
         {
             const int drj = dr + __builtin_amdgcn_sbfe(w1, 10 * (j - 1) + 5, 5);
             const int e_ = dc + j + __builtin_amdgcn_sbfe(w1, 10 * (j - 1), 5);
-            ok = ok && (unsigned)drj < (unsigned)kFwdSpan && (unsigned)e_ < (unsigned)(4 * kFwdQuads);
+            in = in && (unsigned)drj < (unsigned)kFwdSpan && (unsigned)e_ < (unsigned)(4 * kFwdQuads);
         }
+        ok = ok && in;
+        any = any || in;
     }
     const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
+    const int n_in = __builtin_popcountll(__builtin_amdgcn_ballot_w64(any));
     if (lane == 0)
-        flags[(size_t)y * strips_x + strip] = all_ok ? 1 : 0;
+        flags[(size_t)y * strips_x + strip] = all_ok ? kRowInside : (n_in < 16 ? kRowOutside : kRowMixed);
 }
 
 // ps == 0: interleaved destination; otherwise planar with plane stride ps
@@ -880,6 +886,29 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
         for (int c = 0; c < CH; ++c)
             a[c] = make_float4(v[0][c], v[1][c], v[2][c], v[3][c]);
     };
+    // All four groups of an LR row from global memory: one unaligned 16-byte gather per group and plane
+    // where the group is a run of pixels inside the image, pixel by pixel otherwise.
+    auto fetch_global_rows = [&](const uint2 (&gm)[4], int N0, float4 (&a)[4][CH]) {
+        bool run[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+        {
+            const int col0 = 4 * xl + __builtin_amdgcn_sbfe((int)gm[r].x, 0, 15);
+            const int row0 = N0 + r + __builtin_amdgcn_sbfe((int)gm[r].x, 15, 15);
+            run[r] = gm[r].y == 0 && (gm[r].x & kGrpFar) == 0 && (unsigned)row0 < (unsigned)H && col0 >= 0 && col0 + 3 < W;
+            const size_t idx = run[r] ? (size_t)row0 * W + col0 : (size_t)H * W;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+            {
+                const float4_a4 v = *(const float4_a4*)(X + c * ps + idx);
+                a[r][c] = make_float4(v.x, v.y, v.z, v.w);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (!run[r])
+                fetch_global(gm[r], N0 + r, a[r]);
+    };
     auto row_pass = [&](const float4 (&a)[CH], float (&out)[CH]) {
 #pragma unroll
         for (int c = 0; c < CH; ++c)
@@ -914,18 +943,26 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
     // the top of row y and used at its end / in row y+1.
     int s = 0; // ring slot of the first row of the current LR row's window
     packed_floats<CH> yv = *(const packed_floats<CH>*)(yk + (size_t)y0 * w * CH);
-    bool inside = flags[(size_t)y0 * strips_x] != 0;
+    uint8_t place = flags[(size_t)y0 * strips_x];
     for (int y = y0; y < y1; ++y)
     {
         const bool more = y + 1 < y1;
-        const bool inside_next = flags[(size_t)min(y + 1, h - 1) * strips_x] != 0;
+        const uint8_t place_next = flags[(size_t)min(y + 1, h - 1) * strips_x];
         float4 sv[2];
         batch_load(more ? 4 * y + 3 + kFwdMy : H, sv);
         uint2 mn[4];
         load_groups(min(y + 1, h - 1), mn);
         const packed_floats<CH> yn = *(const packed_floats<CH>*)(yk + (size_t)min(y + 1, h - 1) * w * CH);
 
-        if (inside)
+        if (place == kRowOutside)
+        {
+            float4 a[4][CH];
+            fetch_global_rows(mc, 4 * y - 1, a);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                row_pass(a[r], rr[r + 1]);
+        }
+        else if (place == kRowInside)
         {
             // all LDS reads of the LR row in flight before the first row pass
             float4 a[4][CH];
@@ -947,7 +984,7 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
                 row_pass(a, rr[r + 1]);
             }
         }
-        inside = inside_next;
+        place = place_next;
 
         uint32_t sg = 0;
 #pragma unroll
