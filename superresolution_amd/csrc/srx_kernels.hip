@@ -37,6 +37,7 @@
 #include "srx_common.h"
 
 
+#include <atomic>
 #include <cstring>
 
 namespace srx
@@ -1586,14 +1587,25 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
         const int passes = (K + kFwdMaxWaves - 1) / kFwdMaxWaves;
         const int waves = (K + passes - 1) / passes;
         // cut the rows so that one round of resident blocks covers the image
-        static int cus = 0;
+        // per device, set up on first use: CU count and the kernels' dynamic-LDS limit (a per-device attribute)
+        constexpr int kMaxDevices = 64;
+        static std::atomic<int> cus_of[kMaxDevices];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices)
+            return check_launch("forward_sign_lds (device query)");
+        int cus = cus_of[dev].load(std::memory_order_acquire);
         if (cus == 0)
         {
-            int dev = 0;
             hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            if (hipGetDeviceProperties(&prop, dev) != hipSuccess)
                 return check_launch("forward_sign_lds (device query)");
+            if (hipFuncSetAttribute((const void*)k_forward_sign_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)forward_lds_bytes(1)) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_forward_sign_lds<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)forward_lds_bytes(3)) != hipSuccess)
+                return check_launch("forward_sign_lds (LDS size)");
             cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            cus_of[dev].store(cus, std::memory_order_release);
         }
         const int blocks_per_cu = forward_lds_bytes(ch) * 2 <= 160 * 1024 ? 2 : 1;
         const int slots = std::max(1, blocks_per_cu * cus / (strips_x * passes));
@@ -1602,16 +1614,6 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
         const unsigned n_tiles = (unsigned)strips_x * row_groups;
         const dim3 gr(xcd_grid(n_tiles), passes), b(64 * waves);
         const size_t lds = forward_lds_bytes(ch);
-        static bool lds_set = false;
-        if (!lds_set)
-        {
-            if (hipFuncSetAttribute((const void*)k_forward_sign_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)forward_lds_bytes(1)) != hipSuccess ||
-                hipFuncSetAttribute((const void*)k_forward_sign_lds<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)forward_lds_bytes(3)) != hipSuccess)
-                return check_launch("forward_sign_lds (LDS size)");
-            lds_set = true;
-        }
         if (ch == 1)
             hipLaunchKernelGGL(k_forward_sign_lds<1>, gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd, y, signs,
                                K, g, strips_x, rows_per_tile, n_tiles);
