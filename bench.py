@@ -135,9 +135,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # SRX_BENCH_REHEARSE=1: all ranks share GPU 0 and talk over gloo with host copies of the halo - a way to
+    # walk the multi-rank code on a one-GPU box; its numbers mean nothing.
+    rehearse = os.environ.get("SRX_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -161,7 +169,11 @@ def main():
     if world > 1:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        left, right = spans.exchange_halo(own, r, rank, world)
+        if rehearse:
+            left, right = spans.exchange_halo([f.cpu() for f in own], r, rank, world)
+            left, right = [f.to(dev) for f in left], [f.to(dev) for f in right]
+        else:
+            left, right = spans.exchange_halo(own, r, rank, world)
         torch.cuda.synchronize()
         halo_ms = (time.perf_counter() - t0) * 1e3
     else:
@@ -222,7 +234,7 @@ def main():
     fwd_ms, bwd_ms, n_it = sr.kernelTimes()
     sr.set("kernelTiming", 0)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
