@@ -138,7 +138,9 @@ def test_forward_sign(ops, rng, rows, cols, ch, scale, n, sigma):
 
 
 @pytest.mark.parametrize("rows,cols,ch,kind", [(40, 70, 3, "large"), (40, 70, 1, "large"), (36, 130, 3, "jitter"),
-                                               (24, 64, 1, "jitter"), (33, 65, 3, "outside"), (20, 127, 3, "wild")])
+                                               (24, 64, 1, "jitter"), (33, 65, 3, "outside"), (20, 127, 3, "wild"),
+                                               (1, 1, 1, "small"), (2, 3, 3, "small"), (3, 63, 1, "small"),
+                                               (5, 64, 3, "small"), (7, 127, 3, "small"), (4, 126, 1, "small")])
 def test_forward_sign_beyond_the_lds_window(ops, rng, rows, cols, ch, kind):
     """Motions the specialised forward kernel cannot serve from its LDS window (sources more than 15 rows / 16
     columns away, neighbouring pixels whose sources are far apart, sources outside every border): the values
@@ -146,7 +148,9 @@ def test_forward_sign_beyond_the_lds_window(ops, rng, rows, cols, ch, kind):
     scale = 4
     H, W = rows * scale, cols * scale
     X = (rng.random((H, W, ch)) * 255).astype(np.float32)
-    if kind == "large":      # smooth, up to ~40 HR pixels
+    if kind == "small":      # sizes around the kernel's strip of 63 LR columns, down to one pixel
+        rel = smooth_motion(rng, rows, cols, amp=0.7)
+    elif kind == "large":    # smooth, up to ~40 HR pixels
         rel = smooth_motion(rng, rows, cols, amp=5.0)
     elif kind == "jitter":   # neighbouring LR pixels move independently: groups that are not runs, far groups
         rel = smooth_motion(rng, rows, cols, amp=1.0) + rng.standard_normal((rows, cols, 2)).astype(np.float32) * 3.0
