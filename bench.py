@@ -7,8 +7,11 @@
 One step = one steady-state SuperResolution::nextFrame() on one GPU: one new
 low-resolution frame enters the ring, its flow is attached, one output frame is
 solved (180 BTV-L1 iterations over a 2*4+1 frame window) and returned as 8-bit.
-Workload (BASELINE.json configs[3], the configuration the metric is quoted on):
-960x540 RGB -> 3840x2160, scale 4, temporalAreaRadius 4.  Inputs are synthetic
+With read-ahead (the default here, --no-read-ahead turns it off) the frame that
+enters and its flow belong to the next call: they are fetched while this call's
+solve runs; the work per step is the same.
+Workload (the configuration the headline metric is quoted on): 960x540 RGB ->
+3840x2160, scale 4, temporalAreaRadius 4.  Inputs are synthetic
 (superresolution_amd/synth.py), 8-bit, resident in HBM before the timed region.
 
 Multi-GPU: the stream is cut into contiguous spans of output frames, one per
