@@ -132,9 +132,10 @@ class Solver
     size_t last_x_plane_stride() const { return ps_; }
     void release();
 
-    // Optional per-kernel timing with HIP events on the solver's stream: every
-    // iteration's forward and back-projection launches are bracketed by events
-    // that are read back (after a stream synchronise) by collect_timing().
+    // Optional per-kernel timing with HIP events on the solver's stream: the forward
+    // and back-projection launches of every kTimingStride-th iteration are bracketed
+    // by events that are read back (after a stream synchronise) by collect_timing().
+    static constexpr int kTimingStride = 4;
     void enable_timing(bool on) { timing_ = on; }
     bool timing() const { return timing_; }
     int collect_timing(hipStream_t st);
