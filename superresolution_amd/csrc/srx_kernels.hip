@@ -1088,7 +1088,7 @@ __device__ __forceinline__ int sign_of_difference(float t)
 //    ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) reads 16
 //    consecutive 16-byte chunks of one LDS row: conflict-free at any row pitch.
 #ifndef SRX_B_WAVES
-#define SRX_B_WAVES 7
+#define SRX_B_WAVES 6
 #endif
 #ifndef SRX_B_PARK
 #define SRX_B_PARK 2
