@@ -673,7 +673,7 @@ template <int N> struct __attribute__((packed, aligned(4))) packed_floats
 // columns 4x .. 4x+3.  The 5-tap row pass centred on column 4x is
 //     a0*k0 + (L.a3 + a1)*k1 + (L.a2 + a2)*k2
 // with L the lane to the left (lane 0 only serves as lane 1's left neighbour; at the image's left
-// edge reflect101 maps columns -1, -2 to a1, a2).  The wave walks down its LR rows keeping the five
+// edge it hands over columns 1 and 2, where reflect101 sends columns -1 and -2).  The wave walks down its LR rows keeping the five
 // row-pass results of the current LR row in registers (four new HR rows per LR row).  Signs go to
 // the pair plane (layout at the top of this file).
 // The ring is re-used with one barrier per LR row: rows staged during LR row y replace rows that
@@ -716,7 +716,11 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
     const int x = x0 - 1 + lane;          // LR column of this lane
     const int xl = min(max(x, 0), w - 1); // column it loads (clamped copies are never stored)
     const bool owner = active && lane >= 1 && x < w;
-    const bool first = x == 0;
+    // At the image's left edge the row pass of LR column 0 needs columns -1 and -2 of the warped
+    // image, which reflect101 maps to columns 1 and 2.  Lane 0 of the first strip (x = -1, loading
+    // column 0's group like lane 1) therefore delivers the pixel of column 1 in the place of column
+    // 3: its neighbour then finds columns 1 and 2 where it looks for columns -1 and -2.
+    const bool mirror = x == -1;
 
     const int c0 = 4 * (x0 - 1) - kFwdMx;  // HR column of element 0 of the staged rows
     const int rbase = 4 * y0 - 2 - kFwdMy; // HR row in ring slot 0
@@ -824,26 +828,37 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
         {
             const unsigned row_at = row_offset(dr);
             pixel(0, row_at, (unsigned)dc);
+            unsigned e1 = 0;
 #pragma unroll
             for (int j = 1; j < 4; ++j)
             {
-                const unsigned e = (unsigned)(dc + j + __builtin_amdgcn_sbfe(w1, 10 * (j - 1), 5));
+                unsigned e = (unsigned)(dc + j + __builtin_amdgcn_sbfe(w1, 10 * (j - 1), 5));
                 if (checked)
                     far_col = max(far_col, e);
+                if (j == 1)
+                    e1 = e;
+                if (j == 3)
+                    e = mirror ? e1 : e;
                 pixel(j, row_at, e);
             }
         }
         else
         {
             pixel(0, row_offset(dr), (unsigned)dc);
+            unsigned e1 = 0, row1 = 0;
 #pragma unroll
             for (int j = 1; j < 4; ++j)
             {
                 const int drj = dr + __builtin_amdgcn_sbfe(w1, 10 * (j - 1) + 5, 5);
-                const unsigned e = (unsigned)(dc + j + __builtin_amdgcn_sbfe(w1, 10 * (j - 1), 5));
+                unsigned e = (unsigned)(dc + j + __builtin_amdgcn_sbfe(w1, 10 * (j - 1), 5));
                 if (checked)
                     far_row = max(far_row, (unsigned)drj), far_col = max(far_col, e);
-                pixel(j, row_offset(drj), e);
+                unsigned row_at = row_offset(drj);
+                if (j == 1)
+                    e1 = e, row1 = row_at;
+                if (j == 3)
+                    e = mirror ? e1 : e, row_at = mirror ? row1 : row_at;
+                pixel(j, row_at, e);
             }
         }
 #pragma unroll
@@ -885,7 +900,7 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
         }
 #pragma unroll
         for (int c = 0; c < CH; ++c)
-            a[c] = make_float4(v[0][c], v[1][c], v[2][c], v[3][c]);
+            a[c] = make_float4(v[0][c], v[1][c], v[2][c], mirror ? v[1][c] : v[3][c]);
     };
     // All four groups of an LR row from global memory: one unaligned 16-byte gather per group and plane
     // where the group is a run of pixels inside the image, pixel by pixel otherwise.
@@ -909,14 +924,17 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
         for (int r = 0; r < 4; ++r)
             if (!run[r])
                 fetch_global(gm[r], N0 + r, a[r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                a[r][c].w = mirror ? a[r][c].y : a[r][c].w;
     };
     auto row_pass = [&](const float4 (&a)[CH], float (&out)[CH]) {
 #pragma unroll
         for (int c = 0; c < CH; ++c)
         {
-            float l3 = from_left_lane(a[c].w), l2 = from_left_lane(a[c].z);
-            l3 = first ? a[c].y : l3;
-            l2 = first ? a[c].z : l2;
+            const float l3 = from_left_lane(a[c].w), l2 = from_left_lane(a[c].z);
             float sum = a[c].x * k0;
             sum += (l3 + a[c].y) * k1;
             sum += (l2 + a[c].z) * k2;
