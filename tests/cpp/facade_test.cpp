@@ -121,6 +121,30 @@ int main()
         ++n;
     }
     REQUIRE(n == 4);
+
+    // read-ahead with the built-in flow: the same number of frames out, the source pulled one frame early;
+    // 16-bit frames are accepted
+    struct Source16 : IFrameSource
+    {
+        int n, pos = 0;
+        Mat frame;
+        explicit Source16(int n) : n(n), frame(6, 8, 1, SRX_16U) {}
+        void reset() override { pos = 0; }
+        Mat nextFrame() override { return pos++ < n ? frame : Mat(); }
+    };
+    BTV_L1 ahead(-1);
+    ahead.set("temporalAreaRadius", 1);
+    ahead.setReadAhead(true);
+    REQUIRE(ahead.getInt("readAhead") == 1);
+    ahead.setOpticalFlow(createOptFlow_DualTVL1());
+    auto src16 = std::make_shared<Source16>(6);
+    ahead.setFrameSource(src16);
+    REQUIRE(!ahead.nextFrame().empty());
+    REQUIRE(src16->pos == 2 * 1 + 2 + 1); // warm-up reads 2r+2 frames, read-ahead one more
+    int more = 1;
+    while (!ahead.nextFrame().empty())
+        ++more;
+    REQUIRE(more == 6);
     std::puts("facade ok");
     return 0;
 }
