@@ -1242,14 +1242,14 @@ SRX_API int srx_k_forward_sign(const float* X, int hr_rows, int hr_cols, int ch,
         if (int rc = launch_decode_maps(nullptr, bwd_map, hr_rows, hr_cols, nullptr, dec.as<uint32_t>(), st))
             return rc;
         dmaps.p[0] = dec.get();
-        if (int rc = launch_forward_sign(xpl.as<float>(), hr_rows, hr_cols, ch, maps, &dmaps, ys, sg, 1, scale, g, st))
+        if (int rc = launch_forward_sign(xpl.as<float>(), hr_rows, hr_cols, ch, maps, &dmaps, ys, sg, 1, scale, g, 0, st))
             return rc;
         if (int rc = launch_sign_unpair(pairs.as<uint32_t>(), sign_out, hr_rows / 4, hr_cols / 4, st))
             return rc;
         SRX_HIP(hipStreamSynchronize(st)); // the temporaries die with this call
         return SRX_OK;
     }
-    return launch_forward_sign(X, hr_rows, hr_cols, ch, maps, nullptr, ys, sg, 1, scale, g, st);
+    return launch_forward_sign(X, hr_rows, hr_cols, ch, maps, nullptr, ys, sg, 1, scale, g, 0, st);
 }
 
 SRX_API int srx_k_backproject_update(const float* X, float* X_out, int hr_rows, int hr_cols, int ch,

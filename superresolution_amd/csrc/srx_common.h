@@ -89,14 +89,18 @@ inline size_t sign_pair_bytes(int lr_rows, int lr_cols)
     return ((size_t)lr_rows * lr_cols + 1) * 8;
 }
 int launch_sign_pairs(const uint32_t* plain, uint32_t* pairs, int lr_rows, int lr_cols, hipStream_t st);
+// 0: specialised / tiled kernels wherever the parameters allow (default); 1: the plain per-pixel kernels only
+extern int g_kernel_path;
+
 int launch_sign_unpair(const uint32_t* pairs, uint32_t* plain, int lr_rows, int lr_cols, hipStream_t st);
 // sign(y_k - D H M_k X) for K frames in one launch.  With dec_bwd (and an
 // eligible parameter set) the specialised kernel runs; it wants X planar
 // (plane_stride_for) with the zero pixel at index hr_rows*hr_cols of every plane
-// and writes pair planes.
+// and writes pair planes.  Otherwise the generic kernel runs: plain sign planes, X interleaved
+// (generic_plane_stride 0) or planar with that plane stride.
 int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const PtrList& raw_bwd,
                         const PtrList* dec_bwd, const PtrList& y, const MutPtrList& signs, int K, int scale,
-                        const GaussK& g, hipStream_t st);
+                        const GaussK& g, size_t generic_plane_stride, hipStream_t st);
 // With dec_fwd (and an eligible parameter set) the specialised kernel runs; it
 // wants X and X_out planar and the signs as pair planes (sign_pair_bytes).
 int launch_backproject_update(const float* X, float* X_out, int hr_rows, int hr_cols, int ch, const PtrList& raw_fwd,

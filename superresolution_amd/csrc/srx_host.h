@@ -85,8 +85,6 @@ struct Params
 
 const std::string& last_error();
 
-// 0: specialised kernels wherever the parameters allow (default); 1: generic kernels only
-extern int g_kernel_path;
 
 // Validates what the reference only debug-asserts (lib/src/btv_l1.cpp:359-365).
 int validate_params(const Params& p);

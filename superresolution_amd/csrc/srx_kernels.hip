@@ -197,6 +197,23 @@ __device__ __forceinline__ uint32_t decode_fwd(int fx, int fy, int R, int C)
     return (uint32_t)(row * (C >> 2) + col) * 8u | ((uint32_t)(pxi + 5 * pyi) << kFwdLutShift);
 }
 
+// Scale 2, 5-tap blur: a target touches at most 3x3 LR sign cells of a plain plane.
+//   bits 0..23   byte offset of the top-left cell: 4 * (row*w + col)
+//   bits 24..28  weight-table index px + 5*py; per axis: 0 even target (cells c-1, c, c+1 with k2, k0, k2),
+//                1 odd target (cells c, c+1 with k1, k1), 2 target 0 (reflect101 folds the tap at -2 onto the
+//                one at +2: k0, 2*k2), 3 last target (the tap beyond the edge folds back: 2*k1), 4 last but one
+//                (k2, k0 + k2); 25 = all weights 0 (target outside the image)
+__device__ __forceinline__ uint32_t decode_fwd2(int fx, int fy, int R, int C)
+{
+    if ((unsigned)fx >= (unsigned)C || (unsigned)fy >= (unsigned)R)
+        return kFwdLutZero << kFwdLutShift;
+    const int px = fx == 0 ? 2 : fx == C - 1 ? 3 : fx == C - 2 ? 4 : (fx & 1);
+    const int py = fy == 0 ? 2 : fy == R - 1 ? 3 : fy == R - 2 ? 4 : (fy & 1);
+    const int col = px == 0 ? (fx >> 1) - 1 : px == 2 ? 0 : px == 4 ? (fx >> 1) - 1 : (fx >> 1);
+    const int row = py == 0 ? (fy >> 1) - 1 : py == 2 ? 0 : py == 4 ? (fy >> 1) - 1 : (fy >> 1);
+    return (uint32_t)(row * (C >> 1) + col) * 4u | ((uint32_t)(px + 5 * py) << kFwdLutShift);
+}
+
 // upscaleMotions + buildMotionMaps + remap's float->short index conversion
 // (lib/src/btv_l1.cpp:59-101; cv::remap INTER_NEAREST), plus the decoded maps
 // for the specialised kernels when dec_fwd / dec_bwd are given (scale 4 only).
@@ -218,18 +235,19 @@ __global__ void k_build_maps(const float* __restrict__ rel, int rows, int cols, 
     fwd_map[o] = make_short2((short)fx, (short)fy);
     bwd_map[o] = make_short2((short)bx, (short)by);
     if (dec_fwd)
-        dec_fwd[o] = decode_fwd(fx, fy, R, C);
+        dec_fwd[o] = scale == 2 ? decode_fwd2(fx, fy, R, C) : decode_fwd(fx, fy, R, C);
 }
 
 // raw int16 maps -> decoded maps (same rules as k_build_maps), for callers that hold raw maps only
-__global__ void k_decode_maps(const short2* __restrict__ fwd_map, int R, int C, uint32_t* __restrict__ dec_fwd)
+__global__ void k_decode_maps(const short2* __restrict__ fwd_map, int R, int C, int scale,
+                              uint32_t* __restrict__ dec_fwd)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= C || y >= R)
         return;
     const size_t o = (size_t)y * C + x;
-    dec_fwd[o] = decode_fwd(fwd_map[o].x, fwd_map[o].y, R, C);
+    dec_fwd[o] = scale == 2 ? decode_fwd2(fwd_map[o].x, fwd_map[o].y, R, C) : decode_fwd(fwd_map[o].x, fwd_map[o].y, R, C);
 }
 
 // group map of the backward map (layout at the top of this file); one thread per entry
@@ -396,16 +414,16 @@ __global__ void k_btv_regularization(const float* __restrict__ X, int H, int W, 
 
 // a(Y, X) = Xhr(bwd(Y, X)) or 0 outside   (remap NEAREST, constant border)
 template <int CH>
-__device__ __forceinline__ void fetch_warped(const float* __restrict__ X, int H, int W,
+__device__ __forceinline__ void fetch_warped(const float* __restrict__ X, int H, int W, size_t ps,
                                              const short2* __restrict__ map, int Yr, int Xr, float (&o)[CH])
 {
     const short2 m = map[(size_t)Yr * W + Xr];
     if ((unsigned)(int)m.x < (unsigned)W && (unsigned)(int)m.y < (unsigned)H)
     {
-        const float* P = X + ((size_t)m.y * W + m.x) * CH;
+        const size_t pi = (size_t)m.y * W + m.x;
 #pragma unroll
         for (int c = 0; c < CH; ++c)
-            o[c] = P[c];
+            o[c] = X[ps ? c * ps + pi : pi * CH + c];
     }
     else
     {
@@ -418,7 +436,7 @@ __device__ __forceinline__ void fetch_warped(const float* __restrict__ X, int H,
 // Row pass of the separable Gaussian at (Yr, Xc) in OpenCV's operation order:
 // n <= 5: centre*k0 + (l1+r1)*k1 + (l2+r2)*k2; n >= 7: taps left to right.
 template <int CH>
-__device__ __forceinline__ void warped_blur_row(const float* __restrict__ X, int H, int W,
+__device__ __forceinline__ void warped_blur_row(const float* __restrict__ X, int H, int W, size_t ps,
                                                 const short2* __restrict__ map, int Yr, int Xc, const GaussK& g,
                                                 float (&r)[CH])
 {
@@ -426,14 +444,14 @@ __device__ __forceinline__ void warped_blur_row(const float* __restrict__ X, int
     float t[CH], u[CH];
     if (n <= 5)
     {
-        fetch_warped<CH>(X, H, W, map, Yr, Xc, t);
+        fetch_warped<CH>(X, H, W, ps, map, Yr, Xc, t);
 #pragma unroll
         for (int c = 0; c < CH; ++c)
             r[c] = t[c] * g.k[hh];
         for (int j = 1; j <= hh; ++j)
         {
-            fetch_warped<CH>(X, H, W, map, Yr, reflect101(Xc - j, W), t);
-            fetch_warped<CH>(X, H, W, map, Yr, reflect101(Xc + j, W), u);
+            fetch_warped<CH>(X, H, W, ps, map, Yr, reflect101(Xc - j, W), t);
+            fetch_warped<CH>(X, H, W, ps, map, Yr, reflect101(Xc + j, W), u);
 #pragma unroll
             for (int c = 0; c < CH; ++c)
                 r[c] += (t[c] + u[c]) * g.k[hh + j];
@@ -441,13 +459,13 @@ __device__ __forceinline__ void warped_blur_row(const float* __restrict__ X, int
     }
     else
     {
-        fetch_warped<CH>(X, H, W, map, Yr, reflect101(Xc - hh, W), t);
+        fetch_warped<CH>(X, H, W, ps, map, Yr, reflect101(Xc - hh, W), t);
 #pragma unroll
         for (int c = 0; c < CH; ++c)
             r[c] = g.k[0] * t[c];
         for (int j = 1; j < n; ++j)
         {
-            fetch_warped<CH>(X, H, W, map, Yr, reflect101(Xc - hh + j, W), t);
+            fetch_warped<CH>(X, H, W, ps, map, Yr, reflect101(Xc - hh + j, W), t);
 #pragma unroll
             for (int c = 0; c < CH; ++c)
                 r[c] += g.k[j] * t[c];
@@ -457,7 +475,7 @@ __device__ __forceinline__ void warped_blur_row(const float* __restrict__ X, int
 
 // sign(y - D H M X) at one LR pixel, any scale / blur size (lib/src/btv_l1.cpp:428-434)
 template <int CH>
-__device__ __forceinline__ uint32_t forward_sign_generic(const float* __restrict__ X, int H, int W,
+__device__ __forceinline__ uint32_t forward_sign_generic(const float* __restrict__ X, int H, int W, size_t ps,
                                                          const short2* __restrict__ map,
                                                          const float* __restrict__ yk, int x, int y, int scale,
                                                          const GaussK& g)
@@ -467,14 +485,14 @@ __device__ __forceinline__ uint32_t forward_sign_generic(const float* __restrict
     const int hh = g.n >> 1;
     float acc[CH], ra[CH], rb[CH];
     // column pass: centre row first, then symmetric pairs outwards
-    warped_blur_row<CH>(X, H, W, map, Yc, Xc, g, ra);
+    warped_blur_row<CH>(X, H, W, ps, map, Yc, Xc, g, ra);
 #pragma unroll
     for (int c = 0; c < CH; ++c)
         acc[c] = ra[c] * g.k[hh];
     for (int j = 1; j <= hh; ++j)
     {
-        warped_blur_row<CH>(X, H, W, map, reflect101(Yc - j, H), Xc, g, ra);
-        warped_blur_row<CH>(X, H, W, map, reflect101(Yc + j, H), Xc, g, rb);
+        warped_blur_row<CH>(X, H, W, ps, map, reflect101(Yc - j, H), Xc, g, ra);
+        warped_blur_row<CH>(X, H, W, ps, map, reflect101(Yc + j, H), Xc, g, rb);
 #pragma unroll
         for (int c = 0; c < CH; ++c)
             acc[c] += (ra[c] + rb[c]) * g.k[hh + j];
@@ -487,8 +505,9 @@ __device__ __forceinline__ uint32_t forward_sign_generic(const float* __restrict
     return s;
 }
 
+// ps == 0: interleaved X; otherwise planar with plane stride ps
 template <int CH>
-__global__ void k_forward_sign(const float* __restrict__ X, int H, int W, PtrList bwd_maps, PtrList ys,
+__global__ void k_forward_sign(const float* __restrict__ X, int H, int W, size_t ps, PtrList bwd_maps, PtrList ys,
                                MutPtrList signs, int scale, GaussK g)
 {
     const int h = H / scale, w = W / scale;
@@ -498,7 +517,92 @@ __global__ void k_forward_sign(const float* __restrict__ X, int H, int W, PtrLis
     if (x >= w || y >= h)
         return;
     ((uint32_t*)signs.p[k])[(size_t)y * w + x] =
-        forward_sign_generic<CH>(X, H, W, (const short2*)bwd_maps.p[k], (const float*)ys.p[k], x, y, scale, g);
+        forward_sign_generic<CH>(X, H, W, ps, (const short2*)bwd_maps.p[k], (const float*)ys.p[k], x, y, scale, g);
+}
+
+// The same values by tiles, for any scale and blur size: a block warps the HR region that a tile of
+// 32 x 8 LR pixels of one frame needs into LDS once (one gather per HR pixel instead of one per tap),
+// runs the row pass at the decimated columns, then the column pass at the decimated rows.
+constexpr int kTileLrW = 32, kTileLrH = 8;
+
+inline size_t forward_tile_lds_bytes(int ch, int scale, int n)
+{
+    const size_t hr_r = (size_t)(kTileLrH - 1) * scale + n, hr_c = (size_t)(kTileLrW - 1) * scale + n;
+    return (hr_r * hr_c + hr_r * kTileLrW) * ch * sizeof(float);
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_forward_sign_tile(const float* __restrict__ X, int H, int W, size_t ps,
+                                                           PtrList bwd_maps, PtrList ys, MutPtrList signs, int scale,
+                                                           GaussK g)
+{
+    extern __shared__ __align__(16) float tile_lds[];
+    const int h = H / scale, w = W / scale;
+    const int n = g.n, hh = n >> 1;
+    const int hr_r = (kTileLrH - 1) * scale + n, hr_c = (kTileLrW - 1) * scale + n;
+    float* A = tile_lds;                       // [CH][hr_r][hr_c] warped pixels
+    float* R = tile_lds + (size_t)CH * hr_r * hr_c; // [CH][hr_r][kTileLrW] row-pass results
+    const int k = blockIdx.z;
+    const int x0 = blockIdx.x * kTileLrW, y0 = blockIdx.y * kTileLrH;
+    const int X0 = x0 * scale - hh, Y0 = y0 * scale - hh;
+    const short2* map = (const short2*)bwd_maps.p[k];
+    const int tid = threadIdx.x;
+
+    const bool interior = X0 >= 0 && Y0 >= 0 && X0 + hr_c <= W && Y0 + hr_r <= H; // no reflection in this tile
+    for (int idx = tid; idx < hr_r * hr_c; idx += 256)
+    {
+        const int r = idx / hr_c, c = idx - r * hr_c;
+        float v[CH];
+        fetch_warped<CH>(X, H, W, ps, map, interior ? Y0 + r : reflect101(Y0 + r, H),
+                         interior ? X0 + c : reflect101(X0 + c, W), v);
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch)
+            A[(ch * hr_r + r) * hr_c + c] = v[ch];
+    }
+    __syncthreads();
+    // row pass in OpenCV's operation order (see warped_blur_row)
+    for (int idx = tid; idx < hr_r * kTileLrW; idx += 256)
+    {
+        const int r = idx / kTileLrW, xl = idx - r * kTileLrW;
+        const int cc = xl * scale + hh;
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch)
+        {
+            const float* a = A + (ch * hr_r + r) * hr_c;
+            float s;
+            if (n <= 5)
+            {
+                s = a[cc] * g.k[hh];
+                for (int j = 1; j <= hh; ++j)
+                    s += (a[cc - j] + a[cc + j]) * g.k[hh + j];
+            }
+            else
+            {
+                s = g.k[0] * a[cc - hh];
+                for (int j = 1; j < n; ++j)
+                    s += g.k[j] * a[cc - hh + j];
+            }
+            R[(ch * hr_r + r) * kTileLrW + xl] = s;
+        }
+    }
+    __syncthreads();
+    const int xl = tid & (kTileLrW - 1), yl = tid / kTileLrW;
+    const int x = x0 + xl, y = y0 + yl;
+    if (x >= w || y >= h)
+        return;
+    const int rc = yl * scale + hh;
+    const float* yp = (const float*)ys.p[k] + ((size_t)y * w + x) * CH;
+    uint32_t sg = 0;
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch)
+    {
+        const float* rr = R + (size_t)ch * hr_r * kTileLrW + xl;
+        float acc = rr[rc * kTileLrW] * g.k[hh];
+        for (int j = 1; j <= hh; ++j)
+            acc += (rr[(rc - j) * kTileLrW] + rr[(rc + j) * kTileLrW]) * g.k[hh + j];
+        sg |= (uint32_t)((int)dsign(yp[ch], acc) + 1) << (10 * ch);
+    }
+    ((uint32_t*)signs.p[k])[(size_t)y * w + x] = sg;
 }
 
 // Transposed chain.  B(fy, fx) = gauss(zero_insert(sign))(fy, fx) evaluated
@@ -1049,9 +1153,16 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
 // the packed 10-bit fields before they must be unpacked.
 struct FastW
 {
-    uint32_t w[kFwdLutSize][4]; // cells (row, col), (row+1, col), (row, col+1), (row+1, col+1)
+    // scale 4: [0..3] = cells (row, col), (row+1, col), (row, col+1), (row+1, col+1) of a pair-plane read;
+    // scale 2: [3*dy + dx] = cell (row+dy, col+dx) of a plain plane, dy, dx in 0..2
+    uint32_t w[kFwdLutSize][9];
     uint32_t wsum[kFwdLutSize];
     int flush;
+};
+// 12 bytes at any 4-byte aligned address: one global_load_dwordx3
+struct __attribute__((packed, aligned(4))) uint3_a4
+{
+    uint32_t x, y, z;
 };
 
 // 16 bytes at an 8-byte aligned address: one global_load_dwordx4
@@ -1112,8 +1223,9 @@ __device__ __forceinline__ int sign_of_difference(float t)
 #define SRX_B_PARK 2
 #endif
 
-template <int CH>
-__global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
+// FOOT = cells per axis a target can touch: 2 (scale 4, pair plane) or 3 (scale 2, plain plane)
+template <int CH, int FOOT>
+__global__ __launch_bounds__(256, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVES - 1) void k_backproject_update_s4(
     const float* __restrict__ X, float* __restrict__ X_out, int H, int W, size_t ps, PtrList dec_fwd,
     PtrList signs, int K, FastW fw, BtvW bw, double tau, double lambda, int tiles_x, unsigned n_tiles)
 {
@@ -1125,7 +1237,8 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
     constexpr int RV = PITCH / 4;       // 16-byte vectors per LDS row
     constexpr int NV = 3;               // vectors per window row: columns [4tx, 4tx+12) of the LDS row
     __shared__ __attribute__((aligned(16))) float tile[LROWS * PITCH]; // one channel at a time
-    __shared__ uint4 lut[2 * kFwdLutSize]; // [li] = weights, [kFwdLutSize + li].x = their sum
+    // scale 4: [li] = weights, [kFwdLutSize + li].x = their sum; scale 2: [3*li .. 3*li+2] = nine weights, sum, -, -
+    __shared__ uint4 lut[(FOOT == 2 ? 2 : 3) * kFwdLutSize];
     // regulariser values rest while the frame loop runs: the first kPark channels in LDS, the others in registers
     constexpr int kPark = SRX_B_PARK < CH ? SRX_B_PARK : CH;
     __shared__ float park[(kPark > 0 ? kPark : 1) * PXT * 256];
@@ -1156,8 +1269,17 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
 
     if (tid < kFwdLutSize)
     {
-        lut[tid] = make_uint4(fw.w[tid][0], fw.w[tid][1], fw.w[tid][2], fw.w[tid][3]);
-        lut[kFwdLutSize + tid] = make_uint4(fw.wsum[tid], 0, 0, 0);
+        if (FOOT == 2)
+        {
+            lut[tid] = make_uint4(fw.w[tid][0], fw.w[tid][1], fw.w[tid][2], fw.w[tid][3]);
+            lut[kFwdLutSize + tid] = make_uint4(fw.wsum[tid], 0, 0, 0);
+        }
+        else
+        {
+            lut[3 * tid] = make_uint4(fw.w[tid][0], fw.w[tid][1], fw.w[tid][2], fw.w[tid][3]);
+            lut[3 * tid + 1] = make_uint4(fw.w[tid][4], fw.w[tid][5], fw.w[tid][6], fw.w[tid][7]);
+            lut[3 * tid + 2] = make_uint4(fw.w[tid][8], fw.wsum[tid], 0, 0);
+        }
     }
     // ---- BTV regulariser, one channel at a time: the channel's tile of X (+3 px halo) is staged in LDS
     // (branch-free clamped loads, the next channel's issued before this channel's arithmetic starts)
@@ -1304,25 +1426,63 @@ __global__ __launch_bounds__(256, SRX_B_WAVES) void k_backproject_update_s4(
                 next = stream_load((const uint4*)((const uint32_t*)dec_fwd.p[k + 1] + pix));
             const char* sg = (const char*)signs.p[k];
             const uint32_t ev[PXT] = {now.x, now.y, now.z, now.w};
-            uint4_a8 qs[PXT];
-#pragma unroll
-            for (int p = 0; p < PXT; ++p)
-                qs[p] = *(const uint4_a8*)(sg + (ev[p] & kFwdCellMask));
-            __builtin_amdgcn_sched_barrier(0); // all four gathers are in flight before the first is consumed
-#pragma unroll
-            for (int p = 0; p < PXT; ++p)
+            if (FOOT == 2)
             {
-                const uint32_t e = ev[p];
-                const uint4_a8 q = qs[p];
-                const char* le = lutb + ((e >> (kFwdLutShift - 4)) & 0x1F0u);
-                const uint4 wq = *(const uint4*)le;
-                uint32_t v = accv[p];
-                v = mad_u24(q.x, wq.x, v);
-                v = mad_u24(q.y, wq.y, v);
-                v = mad_u24(q.z, wq.z, v);
-                v = mad_u24(q.w, wq.w, v);
-                accv[p] = v;
-                bias[p] += *(const uint32_t*)(le + kFwdLutSize * 16);
+                uint4_a8 qs[PXT];
+#pragma unroll
+                for (int p = 0; p < PXT; ++p)
+                    qs[p] = *(const uint4_a8*)(sg + (ev[p] & kFwdCellMask));
+                __builtin_amdgcn_sched_barrier(0); // all four gathers are in flight before the first is consumed
+#pragma unroll
+                for (int p = 0; p < PXT; ++p)
+                {
+                    const uint32_t e = ev[p];
+                    const uint4_a8 q = qs[p];
+                    const char* le = lutb + ((e >> (kFwdLutShift - 4)) & 0x1F0u);
+                    const uint4 wq = *(const uint4*)le;
+                    uint32_t v = accv[p];
+                    v = mad_u24(q.x, wq.x, v);
+                    v = mad_u24(q.y, wq.y, v);
+                    v = mad_u24(q.z, wq.z, v);
+                    v = mad_u24(q.w, wq.w, v);
+                    accv[p] = v;
+                    bias[p] += *(const uint32_t*)(le + kFwdLutSize * 16);
+                }
+            }
+            else
+            {
+                // three rows of three cells per pixel, two pixels at a time (register budget)
+                const size_t row_bytes = (size_t)(W >> 1) * 4;
+#pragma unroll
+                for (int p0 = 0; p0 < PXT; p0 += 2)
+                {
+                    uint3_a4 qs[2][3];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int r = 0; r < 3; ++r)
+                            qs[p][r] = *(const uint3_a4*)(sg + (ev[p0 + p] & kFwdCellMask) + r * row_bytes);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                    {
+                        const uint32_t e = ev[p0 + p];
+                        const char* le = lutb + ((e >> kFwdLutShift) & 31u) * 48u;
+                        const uint4 w0 = *(const uint4*)le, w1 = *(const uint4*)(le + 16), w2 = *(const uint4*)(le + 32);
+                        uint32_t v = accv[p0 + p];
+                        v = mad_u24(qs[p][0].x, w0.x, v);
+                        v = mad_u24(qs[p][0].y, w0.y, v);
+                        v = mad_u24(qs[p][0].z, w0.z, v);
+                        v = mad_u24(qs[p][1].x, w0.w, v);
+                        v = mad_u24(qs[p][1].y, w1.x, v);
+                        v = mad_u24(qs[p][1].z, w1.y, v);
+                        v = mad_u24(qs[p][2].x, w1.z, v);
+                        v = mad_u24(qs[p][2].y, w1.w, v);
+                        v = mad_u24(qs[p][2].z, w2.x, v);
+                        accv[p0 + p] = v;
+                        bias[p0 + p] += w2.y;
+                    }
+                }
             }
             if (++pending == fw.flush || k + 1 == K)
             {
@@ -1490,9 +1650,9 @@ static int launch_group_maps(const int16_t* bwd_map, uint32_t* dec_bwd, size_t h
 int launch_build_maps(const float* rel, int rows, int cols, int scale, const CubicTables& t, int16_t* fwd_map,
                       int16_t* bwd_map, uint32_t* dec_fwd, uint32_t* dec_bwd, hipStream_t st)
 {
-    if ((dec_fwd || dec_bwd) && scale != 4)
+    if ((dec_bwd && scale != 4) || (dec_fwd && scale != 4 && scale != 2))
     {
-        set_error("build_maps: decoded maps exist for scale 4 only");
+        set_error("build_maps: decoded maps exist for scale 4 (both) and scale 2 (forward) only");
         return 1;
     }
     const dim3 b(64, 4);
@@ -1510,7 +1670,7 @@ int launch_decode_maps(const int16_t* fwd_map, const int16_t* bwd_map, int hr_ro
     if (dec_fwd)
     {
         hipLaunchKernelGGL(k_decode_maps, grid2d(hr_cols, hr_rows, b), b, 0, st, (const short2*)fwd_map, hr_rows,
-                           hr_cols, dec_fwd);
+                           hr_cols, 4, dec_fwd);
         if (int rc = check_launch("decode_maps"))
             return rc;
     }
@@ -1589,7 +1749,7 @@ bool forward_fast_eligible(int hr_rows, int hr_cols, int ch, int scale, const Ga
 
 int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const PtrList& raw_bwd,
                         const PtrList* dec_bwd, const PtrList& y, const MutPtrList& signs, int K, int scale,
-                        const GaussK& g, hipStream_t st)
+                        const GaussK& g, size_t generic_plane_stride, hipStream_t st)
 {
     if (ch != 1 && ch != 3)
     {
@@ -1640,20 +1800,35 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
                                K, g, strips_x, rows_per_tile, n_tiles);
         return check_launch("forward_sign_lds");
     }
+    const size_t tile_lds = forward_tile_lds_bytes(ch, scale, g.n);
+    if (g_kernel_path == 0 && tile_lds <= 64 * 1024)
+    {
+        const int w = hr_cols / scale, h = hr_rows / scale;
+        const dim3 gr((w + kTileLrW - 1) / kTileLrW, (h + kTileLrH - 1) / kTileLrH, K), b(256);
+        if (ch == 1)
+            hipLaunchKernelGGL(k_forward_sign_tile<1>, gr, b, tile_lds, st, X, hr_rows, hr_cols, generic_plane_stride,
+                               raw_bwd, y, signs, scale, g);
+        else
+            hipLaunchKernelGGL(k_forward_sign_tile<3>, gr, b, tile_lds, st, X, hr_rows, hr_cols, generic_plane_stride,
+                               raw_bwd, y, signs, scale, g);
+        return check_launch("forward_sign_tile");
+    }
     const dim3 b(64, 4);
     const dim3 gr = grid2d(hr_cols / scale, hr_rows / scale, b, K);
     if (ch == 1)
-        hipLaunchKernelGGL(k_forward_sign<1>, gr, b, 0, st, X, hr_rows, hr_cols, raw_bwd, y, signs, scale, g);
+        hipLaunchKernelGGL(k_forward_sign<1>, gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride, raw_bwd, y, signs,
+                           scale, g);
     else
-        hipLaunchKernelGGL(k_forward_sign<3>, gr, b, 0, st, X, hr_rows, hr_cols, raw_bwd, y, signs, scale, g);
+        hipLaunchKernelGGL(k_forward_sign<3>, gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride, raw_bwd, y, signs,
+                           scale, g);
     return check_launch("forward_sign");
 }
 
 // The integer path needs every blur weight to be a multiple of 1/16 (true for
 // the sigma = 0 table {1,4,6,4,1}/16).
-static bool make_fast_weights(const GaussK& g, FastW& fw)
+static bool make_fast_weights(const GaussK& g, int scale, FastW& fw)
 {
-    if (g.n != 5)
+    if (g.n != 5 || (scale != 4 && scale != 2))
         return false;
     int ki[3];
     for (int i = 0; i < 3; ++i)
@@ -1663,33 +1838,56 @@ static bool make_fast_weights(const GaussK& g, FastW& fw)
             return false;
         ki[i] = (int)v;
     }
-    // per phase p: slot A carries tap j = {0,-1,-2,+1,-2}[p], slot B only exists for p == 2 (tap +2)
-    const int gA[5] = {ki[0], ki[1], ki[2], ki[1], ki[2]};
-    const int gB[5] = {0, 0, ki[2], 0, 0};
     std::memset(&fw, 0, sizeof(fw));
     uint32_t wmax = 0;
-    for (int py = 0; py < 5; ++py)
-        for (int px = 0; px < 5; ++px)
-        {
-            const int p = px + 5 * py;
-            fw.w[p][0] = gA[px] * gA[py]; // (row, col)
-            fw.w[p][1] = gA[px] * gB[py]; // (row+1, col)
-            fw.w[p][2] = gB[px] * gA[py]; // (row, col+1)
-            fw.w[p][3] = gB[px] * gB[py]; // (row+1, col+1)
-            fw.wsum[p] = fw.w[p][0] + fw.w[p][1] + fw.w[p][2] + fw.w[p][3];
-            wmax = fw.wsum[p] > wmax ? fw.wsum[p] : wmax;
-        }
+    if (scale == 4)
+    {
+        // per phase p: slot A carries tap j = {0,-1,-2,+1,-2}[p], slot B only exists for p == 2 (tap +2)
+        const int gA[5] = {ki[0], ki[1], ki[2], ki[1], ki[2]};
+        const int gB[5] = {0, 0, ki[2], 0, 0};
+        for (int py = 0; py < 5; ++py)
+            for (int px = 0; px < 5; ++px)
+            {
+                const int p = px + 5 * py;
+                fw.w[p][0] = gA[px] * gA[py]; // (row, col)
+                fw.w[p][1] = gA[px] * gB[py]; // (row+1, col)
+                fw.w[p][2] = gB[px] * gA[py]; // (row, col+1)
+                fw.w[p][3] = gB[px] * gB[py]; // (row+1, col+1)
+            }
+    }
+    else
+    {
+        // per phase (decode_fwd2) the weights of the three cells from the base cell on
+        const int ax[5][3] = {{ki[2], ki[0], ki[2]}, {ki[1], ki[1], 0}, {ki[0], 2 * ki[2], 0}, {2 * ki[1], 0, 0},
+                              {ki[2], ki[0] + ki[2], 0}};
+        for (int py = 0; py < 5; ++py)
+            for (int px = 0; px < 5; ++px)
+                for (int dy = 0; dy < 3; ++dy)
+                    for (int dx = 0; dx < 3; ++dx)
+                        fw.w[px + 5 * py][3 * dy + dx] = ax[px][dx] * ax[py][dy];
+    }
+    for (int p = 0; p < 25; ++p)
+    {
+        for (int i = 0; i < 9; ++i)
+            fw.wsum[p] += fw.w[p][i];
+        wmax = fw.wsum[p] > wmax ? fw.wsum[p] : wmax;
+    }
     if (wmax == 0 || 2 * wmax > 1023u)
         return false; // 10-bit fields
     fw.flush = (int)(1023u / (2 * wmax));
     return true;
 }
 
+// Scale 4 reads pair planes (the specialised forward kernel writes them), scale 2 plain planes with one
+// spare row behind the last (cells of weight 0 are still read).
 bool backproject_fast_eligible(int hr_rows, int hr_cols, int ch, int scale, const GaussK& g, const BtvW& w)
 {
     FastW fw;
-    return scale == 4 && w.radius == 3 && (ch == 1 || ch == 3) && hr_rows % 4 == 0 && hr_cols % 4 == 0 &&
-           ((size_t)(hr_rows / 4) * (hr_cols / 4) + 1) * 8 <= (1u << 24) && make_fast_weights(g, fw);
+    if (w.radius != 3 || (ch != 1 && ch != 3) || hr_rows % 4 != 0 || hr_cols % 4 != 0 || !make_fast_weights(g, scale, fw))
+        return false;
+    if (scale == 4)
+        return ((size_t)(hr_rows / 4) * (hr_cols / 4) + 1) * 8 <= (1u << 24);
+    return hr_rows >= 8 && hr_cols >= 8 && ((size_t)(hr_rows / 2 + 1) * (hr_cols / 2) + 4) * 4 <= (1u << 24);
 }
 
 int launch_backproject_update(const float* X, float* X_out, int hr_rows, int hr_cols, int ch, const PtrList& raw_fwd,
@@ -1702,18 +1900,22 @@ int launch_backproject_update(const float* X, float* X_out, int hr_rows, int hr_
         return 1;
     }
     FastW fw;
-    if (dec_fwd && backproject_fast_eligible(hr_rows, hr_cols, ch, scale, g, w) && make_fast_weights(g, fw))
+    if (dec_fwd && backproject_fast_eligible(hr_rows, hr_cols, ch, scale, g, w) && make_fast_weights(g, scale, fw))
     {
         const int tiles_x = (hr_cols + 63) / 64, tiles_y = (hr_rows + 15) / 16;
         const size_t ps = plane_stride_for((size_t)hr_rows * hr_cols);
         const unsigned n_tiles = (unsigned)tiles_x * tiles_y;
         const dim3 gr(xcd_grid(n_tiles)), b(256);
-        if (ch == 1)
-            hipLaunchKernelGGL(k_backproject_update_s4<1>, gr, b, 0, st, X, X_out, hr_rows, hr_cols, ps, *dec_fwd,
-                               signs, K, fw, w, tau, lambda, tiles_x, n_tiles);
+#define SRX_UPD(CHN, FT) hipLaunchKernelGGL((k_backproject_update_s4<CHN, FT>), gr, b, 0, st, X, X_out, hr_rows, hr_cols, ps, *dec_fwd, signs, K, fw, w, tau, lambda, tiles_x, n_tiles)
+        if (ch == 1 && scale == 4)
+            SRX_UPD(1, 2);
+        else if (ch == 1)
+            SRX_UPD(1, 3);
+        else if (scale == 4)
+            SRX_UPD(3, 2);
         else
-            hipLaunchKernelGGL(k_backproject_update_s4<3>, gr, b, 0, st, X, X_out, hr_rows, hr_cols, ps, *dec_fwd,
-                               signs, K, fw, w, tau, lambda, tiles_x, n_tiles);
+            SRX_UPD(3, 3);
+#undef SRX_UPD
         return check_launch("backproject_update_s4");
     }
     const dim3 b(64, 4);

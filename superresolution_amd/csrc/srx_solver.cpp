@@ -218,7 +218,7 @@ int Solver::ensure(int K, int rows, int cols, int ch, int scale, hipStream_t st)
     const size_t x_bytes = plane_stride_for(hr_px) * ch * sizeof(float);
     const size_t sign_bytes = sign_pair_bytes(rows, cols);
     const size_t rel_bytes = (size_t)rows * cols * 2 * sizeof(float);
-    const bool dec = scale == 4 && g_kernel_path == 0;
+    const bool dec = (scale == 4 || scale == 2) && g_kernel_path == 0;
     if ((int)fwd_maps_.size() < K)
     {
         fwd_maps_.resize(K);
@@ -244,8 +244,9 @@ int Solver::ensure(int K, int rows, int cols, int ch, int scale, hipStream_t st)
         {
             if (int rc = dec_fwd_[k].reserve(hr_px * 4))
                 return rc;
-            if (int rc = dec_bwd_[k].reserve(dec_bwd_words(hr_px) * 4))
-                return rc;
+            if (scale == 4)
+                if (int rc = dec_bwd_[k].reserve(dec_bwd_words(hr_px) * 4))
+                    return rc;
         }
         if (signs_[k].capacity() < sign_bytes)
         {
@@ -351,11 +352,13 @@ int Solver::run(const float* const* y, const float* const* rel, int K, int base_
     }
 
     const CubicTables t = tables_.view();
-    // the specialised kernels keep X planar, so they are used together or not at all
-    const bool fast = g_kernel_path == 0 && forward_fast_eligible((int)R, (int)C, ch, s, gauss_) &&
-                      backproject_fast_eligible((int)R, (int)C, ch, s, gauss_, btv_);
-    const bool fastA = fast, fastB = fast;
-    ps_ = fast ? plane_stride_for((size_t)R * C) : 0;
+    // The specialised update kernel keeps X planar.  At scale 4 it reads the pair planes that only the
+    // specialised forward kernel writes, so there the two are used together or not at all; at scale 2 it
+    // reads plain planes, which the generic forward kernel writes (from the planar X).
+    const bool fastB = g_kernel_path == 0 && backproject_fast_eligible((int)R, (int)C, ch, s, gauss_, btv_) &&
+                       (s != 4 || forward_fast_eligible((int)R, (int)C, ch, s, gauss_));
+    const bool fastA = fastB && s == 4;
+    ps_ = fastB ? plane_stride_for((size_t)R * C) : 0;
     PtrList fwd{}, bwd{}, dfwd{}, dbwd{}, ys{}, sg{};
     MutPtrList sgm{};
     for (int k = 0; k < K; ++k)
@@ -398,7 +401,7 @@ int Solver::run(const float* const* y, const float* const* rel, int K, int base_
         if (time_it)
             SRX_HIP(hipEventRecord(events_[3 * timed], st));
         if (int rc = launch_forward_sign(x_[cur_].as<float>(), (int)R, (int)C, ch, bwd, fastA ? &dbwd : nullptr, ys,
-                                         sgm, K, s, gauss_, st))
+                                         sgm, K, s, gauss_, ps_, st))
             return rc;
         if (time_it)
             SRX_HIP(hipEventRecord(events_[3 * timed + 1], st));
