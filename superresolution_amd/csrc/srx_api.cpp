@@ -1239,7 +1239,7 @@ SRX_API int srx_k_forward_sign(const float* X, int hr_rows, int hr_cols, int ch,
         SRX_HIP(hipMemsetAsync(xpl.get(), 0, ps * ch * sizeof(float), st));
         if (int rc = launch_relayout(X, xpl.as<float>(), px, ch, ps, true, st))
             return rc;
-        if (int rc = launch_decode_maps(nullptr, bwd_map, hr_rows, hr_cols, nullptr, dec.as<uint32_t>(), st))
+        if (int rc = launch_decode_maps(nullptr, bwd_map, hr_rows, hr_cols, 4, nullptr, dec.as<uint32_t>(), st))
             return rc;
         dmaps.p[0] = dec.get();
         if (int rc = launch_forward_sign(xpl.as<float>(), hr_rows, hr_cols, ch, maps, &dmaps, ys, sg, 1, scale, g, 0, st))
@@ -1278,11 +1278,13 @@ SRX_API int srx_k_backproject_update(const float* X, float* X_out, int hr_rows, 
         sg.p[k] = signs_host[k];
     }
     if (g_kernel_path == 0 && backproject_fast_eligible(hr_rows, hr_cols, ch, scale, g, bw) &&
-        forward_fast_eligible(hr_rows, hr_cols, ch, scale, g))
+        (scale != 4 || forward_fast_eligible(hr_rows, hr_cols, ch, scale, g)))
     {
-        // the specialised kernels want decoded maps, pair planes of signs, and planar images
+        // the specialised kernels want decoded maps, planar images, and the signs as pair planes (scale 4)
+        // or as plain planes with a spare row (scale 2)
         const size_t px = (size_t)hr_rows * hr_cols, ps = plane_stride_for(px);
-        const size_t padded = sign_pair_bytes(hr_rows / 4, hr_cols / 4);
+        const int lr_rows = hr_rows / scale, lr_cols = hr_cols / scale;
+        const size_t padded = sign_pair_bytes(lr_rows, lr_cols);
         std::vector<DeviceBuffer> dec(K), spad(K);
         DeviceBuffer xin, xout;
         if (int rc = xin.reserve(ps * ch * sizeof(float)))
@@ -1298,9 +1300,15 @@ SRX_API int srx_k_backproject_update(const float* X, float* X_out, int hr_rows, 
                 return rc;
             if (int rc = spad[k].reserve(padded))
                 return rc;
-            if (int rc = launch_sign_pairs(signs_host[k], spad[k].as<uint32_t>(), hr_rows / 4, hr_cols / 4, st))
-                return rc;
-            if (int rc = launch_decode_maps(fwd_maps_host[k], nullptr, hr_rows, hr_cols, dec[k].as<uint32_t>(),
+            if (scale == 4)
+            {
+                if (int rc = launch_sign_pairs(signs_host[k], spad[k].as<uint32_t>(), lr_rows, lr_cols, st))
+                    return rc;
+            }
+            else
+                SRX_HIP(hipMemcpyAsync(spad[k].get(), signs_host[k], (size_t)lr_rows * lr_cols * 4,
+                                       hipMemcpyDeviceToDevice, st));
+            if (int rc = launch_decode_maps(fwd_maps_host[k], nullptr, hr_rows, hr_cols, scale, dec[k].as<uint32_t>(),
                                             nullptr, st))
                 return rc;
             dmaps.p[k] = dec[k].get();

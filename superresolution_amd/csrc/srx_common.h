@@ -67,8 +67,8 @@ inline size_t dec_bwd_words(size_t hr_px)
 }
 int launch_build_maps(const float* rel, int rows, int cols, int scale, const CubicTables& t, int16_t* fwd_map,
                       int16_t* bwd_map, uint32_t* dec_fwd, uint32_t* dec_bwd, hipStream_t st);
-int launch_decode_maps(const int16_t* fwd_map, const int16_t* bwd_map, int hr_rows, int hr_cols, uint32_t* dec_fwd,
-                       uint32_t* dec_bwd, hipStream_t st);
+int launch_decode_maps(const int16_t* fwd_map, const int16_t* bwd_map, int hr_rows, int hr_cols, int scale,
+                       uint32_t* dec_fwd, uint32_t* dec_bwd, hipStream_t st);
 // plane_stride == 0: interleaved HR image; otherwise planar (plane c at c * plane_stride floats)
 int launch_resize_cubic(const float* src, int srows, int scols, int ch, const CubicTables& t, float* dst, int drows,
                         int dcols, size_t plane_stride, hipStream_t st);

@@ -1663,14 +1663,14 @@ int launch_build_maps(const float* rel, int rows, int cols, int scale, const Cub
     return dec_bwd ? launch_group_maps(bwd_map, dec_bwd, (size_t)rows * scale * cols * scale, cols * scale, st) : 0;
 }
 
-int launch_decode_maps(const int16_t* fwd_map, const int16_t* bwd_map, int hr_rows, int hr_cols, uint32_t* dec_fwd,
-                       uint32_t* dec_bwd, hipStream_t st)
+int launch_decode_maps(const int16_t* fwd_map, const int16_t* bwd_map, int hr_rows, int hr_cols, int scale,
+                       uint32_t* dec_fwd, uint32_t* dec_bwd, hipStream_t st)
 {
     const dim3 b(64, 4);
     if (dec_fwd)
     {
         hipLaunchKernelGGL(k_decode_maps, grid2d(hr_cols, hr_rows, b), b, 0, st, (const short2*)fwd_map, hr_rows,
-                           hr_cols, 4, dec_fwd);
+                           hr_cols, scale, dec_fwd);
         if (int rc = check_launch("decode_maps"))
             return rc;
     }

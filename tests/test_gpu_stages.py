@@ -191,7 +191,13 @@ def _backproject_ref(X, signs, fwd_floats, scale, gk, B, w, tau, lam):
                                                               (16, 16, 3, 4, 7, 0.0, 2, 0.03),
                                                               (16, 12, 1, 4, 5, 1.3, 3, 0.0),
                                                               (10, 10, 3, 2, 9, 2.0, 2, 0.03),
-                                                              (9, 9, 1, 2, 5, 0.7, 9, 0.03)])
+                                                              (9, 9, 1, 2, 5, 0.7, 9, 0.03),
+                                                              # scale 2 with the dyadic 5-tap blur: the update
+                                                              # kernel's 3x3-cell variant, down to its minimum size
+                                                              (14, 22, 1, 2, 5, 0.0, 17, 0.03),
+                                                              (4, 4, 3, 2, 5, 0.0, 3, 0.03),
+                                                              (16, 34, 3, 2, 5, 0.0, 4, 0.0),
+                                                              (6, 66, 3, 2, 5, 0.0, 2, 0.03)])
 def test_backproject_update(ops, rng, rows, cols, ch, scale, n, sigma, K, lam):
     H, W = rows * scale, cols * scale
     B, alpha, tau = 7, 0.7, 1.3
