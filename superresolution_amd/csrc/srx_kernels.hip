@@ -531,46 +531,63 @@ inline size_t forward_tile_lds_bytes(int ch, int scale, int n)
     return (hr_r * hr_c + hr_r * kTileLrW) * ch * sizeof(float);
 }
 
-template <int CH>
+// N5: the blur has five taps (loops unrolled); otherwise any size
+template <int CH, bool N5>
 __global__ __launch_bounds__(256) void k_forward_sign_tile(const float* __restrict__ X, int H, int W, size_t ps,
                                                            PtrList bwd_maps, PtrList ys, MutPtrList signs, int scale,
                                                            GaussK g)
 {
     extern __shared__ __align__(16) float tile_lds[];
     const int h = H / scale, w = W / scale;
-    const int n = g.n, hh = n >> 1;
+    const int n = N5 ? 5 : g.n, hh = n >> 1;
     const int hr_r = (kTileLrH - 1) * scale + n, hr_c = (kTileLrW - 1) * scale + n;
-    float* A = tile_lds;                       // [CH][hr_r][hr_c] warped pixels
-    float* R = tile_lds + (size_t)CH * hr_r * hr_c; // [CH][hr_r][kTileLrW] row-pass results
+    const int n_px = hr_r * hr_c;
+    float* A = tile_lds;                // [CH][hr_r][hr_c] warped pixels
+    float* R = tile_lds + CH * n_px;    // [CH][hr_r][kTileLrW] row-pass results
     const int k = blockIdx.z;
     const int x0 = blockIdx.x * kTileLrW, y0 = blockIdx.y * kTileLrH;
     const int X0 = x0 * scale - hh, Y0 = y0 * scale - hh;
     const short2* map = (const short2*)bwd_maps.p[k];
     const int tid = threadIdx.x;
 
+    // warp: pixel idx = tid, tid + 256, ... of the region; (r, c) advance without divisions
     const bool interior = X0 >= 0 && Y0 >= 0 && X0 + hr_c <= W && Y0 + hr_r <= H; // no reflection in this tile
-    for (int idx = tid; idx < hr_r * hr_c; idx += 256)
+    const int r_step = 256 / hr_c, c_step = 256 - r_step * hr_c;
+    int r = tid / hr_c, c = tid - r * hr_c;
+    for (int idx = tid; idx < n_px; idx += 256)
     {
-        const int r = idx / hr_c, c = idx - r * hr_c;
-        float v[CH];
-        fetch_warped<CH>(X, H, W, ps, map, interior ? Y0 + r : reflect101(Y0 + r, H),
-                         interior ? X0 + c : reflect101(X0 + c, W), v);
+        const int Yr = interior ? Y0 + r : reflect101(Y0 + r, H), Xr = interior ? X0 + c : reflect101(X0 + c, W);
+        const short2 m = map[(unsigned)(Yr * W + Xr)];
+        const bool in = (unsigned)(int)m.x < (unsigned)W && (unsigned)(int)m.y < (unsigned)H;
+        const unsigned pi = in ? (unsigned)((int)m.y * W + (int)m.x) : 0u;
 #pragma unroll
         for (int ch = 0; ch < CH; ++ch)
-            A[(ch * hr_r + r) * hr_c + c] = v[ch];
+        {
+            const float v = X[ps ? ch * ps + pi : (size_t)pi * CH + ch];
+            A[ch * n_px + idx] = in ? v : 0.0f; // remap's constant border
+        }
+        r += r_step, c += c_step;
+        if (c >= hr_c)
+            c -= hr_c, ++r;
     }
     __syncthreads();
     // row pass in OpenCV's operation order (see warped_blur_row)
     for (int idx = tid; idx < hr_r * kTileLrW; idx += 256)
     {
-        const int r = idx / kTileLrW, xl = idx - r * kTileLrW;
+        const int rr_ = idx / kTileLrW, xl = idx - rr_ * kTileLrW;
         const int cc = xl * scale + hh;
 #pragma unroll
         for (int ch = 0; ch < CH; ++ch)
         {
-            const float* a = A + (ch * hr_r + r) * hr_c;
+            const float* a = A + ch * n_px + rr_ * hr_c;
             float s;
-            if (n <= 5)
+            if (N5)
+            {
+                s = a[cc] * g.k[2];
+                s += (a[cc - 1] + a[cc + 1]) * g.k[3];
+                s += (a[cc - 2] + a[cc + 2]) * g.k[4];
+            }
+            else if (n <= 5)
             {
                 s = a[cc] * g.k[hh];
                 for (int j = 1; j <= hh; ++j)
@@ -582,7 +599,7 @@ __global__ __launch_bounds__(256) void k_forward_sign_tile(const float* __restri
                 for (int j = 1; j < n; ++j)
                     s += g.k[j] * a[cc - hh + j];
             }
-            R[(ch * hr_r + r) * kTileLrW + xl] = s;
+            R[(ch * hr_r + rr_) * kTileLrW + xl] = s;
         }
     }
     __syncthreads();
@@ -596,10 +613,20 @@ __global__ __launch_bounds__(256) void k_forward_sign_tile(const float* __restri
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch)
     {
-        const float* rr = R + (size_t)ch * hr_r * kTileLrW + xl;
-        float acc = rr[rc * kTileLrW] * g.k[hh];
-        for (int j = 1; j <= hh; ++j)
-            acc += (rr[(rc - j) * kTileLrW] + rr[(rc + j) * kTileLrW]) * g.k[hh + j];
+        const float* q = R + ch * hr_r * kTileLrW + xl;
+        float acc;
+        if (N5)
+        {
+            acc = q[rc * kTileLrW] * g.k[2];
+            acc += (q[(rc - 1) * kTileLrW] + q[(rc + 1) * kTileLrW]) * g.k[3];
+            acc += (q[(rc - 2) * kTileLrW] + q[(rc + 2) * kTileLrW]) * g.k[4];
+        }
+        else
+        {
+            acc = q[rc * kTileLrW] * g.k[hh];
+            for (int j = 1; j <= hh; ++j)
+                acc += (q[(rc - j) * kTileLrW] + q[(rc + j) * kTileLrW]) * g.k[hh + j];
+        }
         sg |= (uint32_t)((int)dsign(yp[ch], acc) + 1) << (10 * ch);
     }
     ((uint32_t*)signs.p[k])[(size_t)y * w + x] = sg;
@@ -1801,16 +1828,20 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
         return check_launch("forward_sign_lds");
     }
     const size_t tile_lds = forward_tile_lds_bytes(ch, scale, g.n);
-    if (g_kernel_path == 0 && tile_lds <= 64 * 1024)
+    if (g_kernel_path == 0 && tile_lds <= 64 * 1024 && (size_t)hr_rows * hr_cols < (1u << 31))
     {
         const int w = hr_cols / scale, h = hr_rows / scale;
         const dim3 gr((w + kTileLrW - 1) / kTileLrW, (h + kTileLrH - 1) / kTileLrH, K), b(256);
-        if (ch == 1)
-            hipLaunchKernelGGL(k_forward_sign_tile<1>, gr, b, tile_lds, st, X, hr_rows, hr_cols, generic_plane_stride,
-                               raw_bwd, y, signs, scale, g);
+#define SRX_TILE(CHN, FIVE) hipLaunchKernelGGL((k_forward_sign_tile<CHN, FIVE>), gr, b, tile_lds, st, X, hr_rows, hr_cols, generic_plane_stride, raw_bwd, y, signs, scale, g)
+        if (ch == 1 && g.n == 5)
+            SRX_TILE(1, true);
+        else if (ch == 1)
+            SRX_TILE(1, false);
+        else if (g.n == 5)
+            SRX_TILE(3, true);
         else
-            hipLaunchKernelGGL(k_forward_sign_tile<3>, gr, b, tile_lds, st, X, hr_rows, hr_cols, generic_plane_stride,
-                               raw_bwd, y, signs, scale, g);
+            SRX_TILE(3, false);
+#undef SRX_TILE
         return check_launch("forward_sign_tile");
     }
     const dim3 b(64, 4);
