@@ -4,6 +4,7 @@
  * cfg2 / cfg4 sizes (480x270 and 960x540 RGB, window 9): the specialised kernels against the generic
    kernels, bit-exact - two independent GPU implementations, the generic one pinned to the oracle by
    the small-size tests.
+ * cfg5 size (1920x1080 RGB -> 3840x2160, scale 2, window 17): the same comparison for the scale-2 kernels.
  * cfg4 size: the fixed point (lambda = 0, one frame, zero motion, y = D H X evaluated by the same
    operations) stays fixed, and a solve with lambda = 0 and zero motion is the same for every window
    frame order (the sum over frames is an integer sum).
@@ -18,11 +19,11 @@ import oracle
 pytestmark = pytest.mark.gpu
 
 
-def _sequence(K, rows, cols, ch, seed):
+def _sequence(K, rows, cols, ch, seed, scale=4):
     import torch
     from superresolution_amd import synth
 
-    lr, flows, _ = synth.make_sequence(K, rows, cols, ch, 4, seed=seed, device="cuda")
+    lr, flows, _ = synth.make_sequence(K, rows, cols, ch, scale, seed=seed, device="cuda")
     return [f.to(torch.float32) for f in lr], flows
 
 
@@ -60,6 +61,20 @@ def test_specialised_and_generic_kernels_agree_at_full_size(rows, cols, iters):
     assert torch.equal(full_f, full_g)
     assert torch.equal(out_f, out_g)
     assert full_f.shape == (rows * 4, cols * 4, 3) and out_f.shape == (rows * 4 - 14, cols * 4 - 14, 3)
+
+
+def test_cfg5_size_scale_2_window_17():
+    """1920x1080 RGB -> 3840x2160, scale 2, 17 frames: the tiled forward kernel and the update kernel's
+    3x3-cell variant against the per-pixel kernels."""
+    import torch
+
+    rows, cols, K = 1080, 1920, 17
+    y, flows = _sequence(K, rows, cols, 3, seed=55, scale=2)
+    out_f, full_f = _solve(y, flows, 8, 0, iterations=2, scale=2)
+    out_g, full_g = _solve(y, flows, 8, 1, iterations=2, scale=2)
+    assert torch.equal(full_f, full_g)
+    assert torch.equal(out_f, out_g)
+    assert full_f.shape == (rows * 2, cols * 2, 3)
 
 
 def test_fixed_point_at_cfg4_size():
