@@ -1173,6 +1173,115 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
     }
 }
 
+// value held by lane+1 of the wave (0 in lane 63)
+__device__ __forceinline__ float from_right_lane(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xF, 0xF, true));
+}
+
+// Forward chain at scale 2, 5-tap blur, planar X: one wave per (strip of 62 LR columns, group of LR
+// rows, window frame).  Lane l works on LR column x = x0 - 1 + l and holds, per HR row and plane, the
+// warped pixels of HR columns 2x, 2x+1 (one 8-byte gather where the two sources are neighbours); the
+// row pass centred on column 2x is
+//     a0*k0 + (L.a1 + a1)*k1 + (L.a0 + R.a0)*k2
+// with L, R the lanes to the left and right (lanes 0 and 63 only serve as neighbours).  reflect101 at
+// the image edges: the left neighbour of column 0 delivers columns 2 and 1 in the places of -2 and
+// -1; the right neighbour of the last column is a clamped copy of it, whose first pixel is column
+// W-2, where W reflects to.  Rows are reflected when they are fetched.  The wave walks down its LR
+// rows keeping the five row-pass results of the current LR row in registers (two new HR rows per LR
+// row).  Writes plain sign planes.
+#ifndef SRX_A2S_ROWS
+#define SRX_A2S_ROWS 12
+#endif
+constexpr int kFwd2Strip = 62, kFwd2Rows = SRX_A2S_ROWS;
+
+template <int CH>
+__global__ __launch_bounds__(64) void k_forward_sign_s2(const float* __restrict__ X, int H, int W, size_t ps,
+                                                        PtrList bwd_maps, PtrList ys, MutPtrList signs, int K, GaussK g,
+                                                        int strips_x, unsigned n_items)
+{
+    const unsigned item = xcd_contiguous(blockIdx.x, n_items);
+    if (item >= n_items)
+        return;
+    const int k = item % K;
+    const unsigned tile = item / K;
+    const int strip = tile % strips_x, rg = tile / strips_x;
+    const int h = H >> 1, w = W >> 1;
+    const int lane = threadIdx.x;
+    const int x0 = strip * kFwd2Strip, y0 = rg * kFwd2Rows;
+    const int y1 = min(y0 + kFwd2Rows, h);
+    const int x = x0 - 1 + lane;
+    const int xl = min(max(x, 0), w - 1);
+    const bool owner = lane >= 1 && lane <= kFwd2Strip && x < w;
+    const bool mirror = x == -1; // delivers columns 2 and 1
+    const int col0 = mirror ? 2 : 2 * xl, col1 = mirror ? 1 : 2 * xl + 1;
+    const short2* map = (const short2*)bwd_maps.p[k];
+    const float* yk = (const float*)ys.p[k] + (size_t)xl * CH;
+    uint32_t* sp = (uint32_t*)signs.p[k] + xl;
+    const float k0 = g.k[2], k1 = g.k[3], k2 = g.k[4];
+    const unsigned zero_px = (unsigned)(H * W);
+
+    // row pass of HR row Y (reflected into the image)
+    auto hr_row = [&](int Y, float (&out)[CH]) {
+        const short2* mrow = map + (size_t)reflect101(Y, H) * W;
+        const short2 m0 = mrow[col0], m1 = mrow[col1];
+        const bool in0 = (unsigned)(int)m0.x < (unsigned)W && (unsigned)(int)m0.y < (unsigned)H;
+        const bool in1 = (unsigned)(int)m1.x < (unsigned)W && (unsigned)(int)m1.y < (unsigned)H;
+        const unsigned i0 = in0 ? (unsigned)((int)m0.y * W + (int)m0.x) : zero_px;
+        const unsigned i1 = in1 ? (unsigned)((int)m1.y * W + (int)m1.x) : zero_px;
+        float a0[CH], a1[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+        {
+            const packed_floats<2> v = *(const packed_floats<2>*)(X + c * ps + i0); // the zero pixel is padded
+            a0[c] = v.v[0], a1[c] = v.v[1];
+        }
+        if (i1 != i0 + 1 || !in0)
+        {
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                a1[c] = X[c * ps + i1];
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+        {
+            const float l1 = from_left_lane(a1[c]), l0 = from_left_lane(a0[c]), r0 = from_right_lane(a0[c]);
+            float sum = a0[c] * k0;
+            sum += (l1 + a1[c]) * k1;
+            sum += (l0 + r0) * k2;
+            out[c] = sum;
+        }
+    };
+
+    float rr[5][CH];
+    hr_row(2 * y0 - 2, rr[0]);
+    hr_row(2 * y0 - 1, rr[1]);
+    hr_row(2 * y0, rr[2]);
+    for (int y = y0; y < y1; ++y)
+    {
+        float yv[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            yv[c] = yk[(size_t)y * w * CH + c];
+        hr_row(2 * y + 1, rr[3]);
+        hr_row(2 * y + 2, rr[4]);
+        uint32_t sg = 0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+        {
+            float sum = rr[2][c] * k0;
+            sum += (rr[1][c] + rr[3][c]) * k1;
+            sum += (rr[0][c] + rr[4][c]) * k2;
+            sg |= (uint32_t)((int)dsign(yv[c], sum) + 1) << (10 * c);
+        }
+        if (owner)
+            stream_store(sp + (size_t)y * w, sg);
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            rr[0][c] = rr[2][c], rr[1][c] = rr[3][c], rr[2][c] = rr[4][c];
+    }
+}
+
 // Integer weights of the transposed 5-tap blur for dyadic kernels (k*16 integer):
 // per weight-table index the weights of the 2x2 block of sign cells, in units of
 // 1/256 and in the order of a pair-plane read, and their sum (the last entry is
@@ -1826,6 +1935,21 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
             hipLaunchKernelGGL(k_forward_sign_lds<3>, gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd, y, signs,
                                K, g, strips_x, rows_per_tile, n_tiles);
         return check_launch("forward_sign_lds");
+    }
+    if (g_kernel_path == 0 && scale == 2 && g.n == 5 && generic_plane_stride != 0 && hr_cols >= 8 && hr_rows >= 8 &&
+        hr_rows % 2 == 0 && hr_cols % 2 == 0 && (size_t)hr_rows * hr_cols < (1u << 31))
+    {
+        const int w = hr_cols / 2, h = hr_rows / 2;
+        const int strips_x = (w + kFwd2Strip - 1) / kFwd2Strip, row_groups = (h + kFwd2Rows - 1) / kFwd2Rows;
+        const unsigned n_items = (unsigned)strips_x * row_groups * K;
+        const dim3 gr(xcd_grid(n_items)), b(64);
+        if (ch == 1)
+            hipLaunchKernelGGL(k_forward_sign_s2<1>, gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride, raw_bwd, y,
+                               signs, K, g, strips_x, n_items);
+        else
+            hipLaunchKernelGGL(k_forward_sign_s2<3>, gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride, raw_bwd, y,
+                               signs, K, g, strips_x, n_items);
+        return check_launch("forward_sign_s2");
     }
     const size_t tile_lds = forward_tile_lds_bytes(ch, scale, g.n);
     if (g_kernel_path == 0 && tile_lds <= 64 * 1024 && (size_t)hr_rows * hr_cols < (1u << 31))
