@@ -1249,6 +1249,21 @@ SRX_API int srx_k_forward_sign(const float* X, int hr_rows, int hr_cols, int ch,
         SRX_HIP(hipStreamSynchronize(st)); // the temporaries die with this call
         return SRX_OK;
     }
+    if (g_kernel_path == 0 && scale == 2 && g.n == 5)
+    {
+        // the scale-2 forward kernel reads X planar (with the zero pixel behind every plane)
+        const size_t px = (size_t)hr_rows * hr_cols, ps = plane_stride_for(px);
+        DeviceBuffer xpl;
+        if (int rc = xpl.reserve(ps * ch * sizeof(float)))
+            return rc;
+        SRX_HIP(hipMemsetAsync(xpl.get(), 0, ps * ch * sizeof(float), st));
+        if (int rc = launch_relayout(X, xpl.as<float>(), px, ch, ps, true, st))
+            return rc;
+        if (int rc = launch_forward_sign(xpl.as<float>(), hr_rows, hr_cols, ch, maps, nullptr, ys, sg, 1, scale, g, ps, st))
+            return rc;
+        SRX_HIP(hipStreamSynchronize(st));
+        return SRX_OK;
+    }
     return launch_forward_sign(X, hr_rows, hr_cols, ch, maps, nullptr, ys, sg, 1, scale, g, 0, st);
 }
 

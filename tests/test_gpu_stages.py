@@ -117,7 +117,11 @@ def _forward_ref(X, bwd_float, y, scale, gk):
 @pytest.mark.parametrize("rows,cols,ch,scale,n,sigma", [(24, 32, 1, 4, 5, 0.0), (17, 21, 3, 4, 5, 0.0),
                                                         (20, 18, 3, 2, 5, 0.0), (12, 14, 1, 3, 3, 0.0),
                                                         (16, 16, 3, 4, 7, 0.0), (16, 12, 1, 4, 5, 1.3),
-                                                        (10, 10, 3, 2, 9, 2.0), (8, 8, 1, 4, 1, 0.0)])
+                                                        (10, 10, 3, 2, 9, 2.0), (8, 8, 1, 4, 1, 0.0),
+                                                        # the scale-2 forward kernel: strip boundary at 62 LR
+                                                        # columns, minimum size, a non-dyadic blur
+                                                        (9, 62, 3, 2, 5, 0.0), (13, 63, 1, 2, 5, 0.0),
+                                                        (4, 4, 3, 2, 5, 0.0), (11, 130, 3, 2, 5, 1.1)])
 def test_forward_sign(ops, rng, rows, cols, ch, scale, n, sigma):
     H, W = rows * scale, cols * scale
     X = (rng.random((H, W, ch)) * 255).astype(np.float32)
