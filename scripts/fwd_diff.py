@@ -1,10 +1,8 @@
 """Where do the specialised and the generic forward kernels disagree? (development aid)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 from superresolution_amd import ops
-import oracle
 rows, cols, ch, scale = [int(v) for v in (sys.argv[1:5] or (24, 32, 1, 4))]
 amp = float(sys.argv[5]) if len(sys.argv) > 5 else 3.0
 rng = np.random.default_rng(7)
@@ -12,7 +10,7 @@ H, W = rows * scale, cols * scale
 X = (rng.random((H, W, ch)) * 255).astype(np.float32)
 yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float32)
 rel = np.stack([amp * np.sin(yy / 9 + xx / 13), amp * np.cos(yy / 11 - xx / 7)], -1).astype(np.float32)
-gk = oracle.gaussian_kernel(5, 0.0)
+gk = ops.gaussian_kernel(5, 0.0)
 y = (rng.random((rows, cols, ch)) * 255).astype(np.float32)
 d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 _, bwd_map = ops.build_maps(d(rel), scale)

@@ -3,11 +3,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from superresolution_amd import ops
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-import oracle
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-gk = oracle.gaussian_kernel(5, 0.0)
+gk = ops.gaussian_kernel(5, 0.0)
 d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 bad = 0
 for it in range(n):
