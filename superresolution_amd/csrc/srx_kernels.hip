@@ -23,17 +23,21 @@
 //                             columns 4x .. 4x+3, then all "word 1" in the
 //                             same order - the forward kernel reads an LR
 //                             pixel's four rows with two 16-byte loads;
-//                   forward:  see kFwd* below.
+//                   forward:  see kFwd* below (scale 4) and decode_fwd2
+//                             (scale 2).
 //   signs         one uint32 word per LR pixel and window frame: sign+1 (0,1,2)
-//                 of channel c in bits 10c..10c+1.  Generic kernels keep a
-//                 plain plane of words.  The specialised kernels keep a "pair
+//                 of channel c in bits 10c..10c+1.  Generic and scale-2 kernels
+//                 keep a plain plane of words (the scale-2 update kernel reads
+//                 one spare row behind it).  The scale-4 kernels keep a "pair
 //                 plane": cell (y, x) is the two words {S(y, x), S(y+1, x)},
 //                 so that one 16-byte read at a cell returns the 2x2 block
 //                 {S(y,x), S(y+1,x), S(y,x+1), S(y+1,x+1)}; rows*cols + 1
 //                 cells.
 //
-// Two families of kernels compute the same values: generic ones (any scale,
-// blur size, BTV size) and specialised ones (scale 4, 5-tap blur, BTV 7).
+// Several kernels compute the same values: per-pixel ones (any scale, blur
+// size, BTV size: the in-library reference), a tiled forward kernel (any scale
+// and blur size), and specialised pairs for scale 4 and scale 2 with the 5-tap
+// blur and BTV size 7.
 #include "srx_common.h"
 
 
