@@ -640,14 +640,24 @@ __global__ __launch_bounds__(256) void k_forward_sign_tile(const float* __restri
 // lazily: the zero-inserted image is non-zero only where both coordinates are
 // multiples of scale.
 // SS = words per cell: 1 for a plain plane, 2 for a pair plane
+// v % scale == 0 and v / scale for v >= 0 without an integer division when scale is a power of two
+__device__ __forceinline__ bool on_lr_grid(int v, int scale)
+{
+    return (scale & (scale - 1)) == 0 ? (v & (scale - 1)) == 0 : v % scale == 0;
+}
+__device__ __forceinline__ int to_lr(int v, int scale)
+{
+    return (scale & (scale - 1)) == 0 ? v >> (31 - __clz(scale)) : v / scale;
+}
+
 template <int CH, int SS = 1>
 __device__ __forceinline__ void sign_at(const uint32_t* __restrict__ sg, int w, int scale, int Yr, int Xr,
                                         float (&o)[CH])
 {
     // caller guarantees Yr % scale == 0
-    if (Xr % scale == 0)
+    if (on_lr_grid(Xr, scale))
     {
-        const uint32_t s = sg[((size_t)(Yr / scale) * w + (Xr / scale)) * SS];
+        const uint32_t s = sg[((size_t)to_lr(Yr, scale) * w + to_lr(Xr, scale)) * SS];
 #pragma unroll
         for (int c = 0; c < CH; ++c)
             o[c] = (float)((int)((s >> (10 * c)) & 3u) - 1);
@@ -664,14 +674,14 @@ template <int CH, int SS = 1>
 __device__ __forceinline__ void upsampled_blur_row(const uint32_t* __restrict__ sg, int W, int scale, int Yr, int fx,
                                                    const GaussK& g, float (&r)[CH])
 {
-    if (Yr % scale != 0)
+    if (!on_lr_grid(Yr, scale))
     {
 #pragma unroll
         for (int c = 0; c < CH; ++c)
             r[c] = 0.0f;
         return;
     }
-    const int w = W / scale;
+    const int w = to_lr(W, scale);
     const int n = g.n, hh = n >> 1;
     float t[CH], u[CH];
     if (n <= 5)
