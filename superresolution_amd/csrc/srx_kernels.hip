@@ -82,11 +82,6 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 // Loads and stores of data that is touched once per launch (maps, signs on their way out): marked
 // non-temporal so that they do not push the lines of X, which every window frame gathers again, out of L2.
-__device__ __forceinline__ uint2 stream_load(const uint2* p)
-{
-    const v2u v = __builtin_nontemporal_load((const v2u*)p);
-    return make_uint2(v.x, v.y);
-}
 __device__ __forceinline__ uint4 stream_load(const uint4* p)
 {
     const v4u v = __builtin_nontemporal_load((const v4u*)p);
