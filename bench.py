@@ -133,6 +133,25 @@ def cpu_baseline(args, lr_u8, flows, base):
     return out
 
 
+def copy_ceiling_gbs(dev) -> float:
+    """Read + write rate of a plain device-to-device copy of 1 GiB (outside the timed region): what a kernel
+    that only streams can reach on this GPU, to set beside the 8 TB/s spec peak."""
+    n = 1 << 28
+    src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * 4 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -297,6 +316,11 @@ def main():
         }
         if args.no_kernel_timing:
             del line["roofline"]
+        else:
+            ceiling = copy_ceiling_gbs(dev)
+            line["roofline"]["copy_ceiling"] = {"value": round(ceiling, 1), "unit": "GB/s",
+                                                "what": "device-to-device copy of 1 GiB, read + write bytes",
+                                                "frac_of_ceiling": line["roofline"]["achieved"] / ceiling}
         if world == 1 and not args.no_cpu_baseline:
             base = min(r, len(frames) - 1)
             win = frames[:2 * r + 1]
