@@ -79,7 +79,10 @@ enum
 {
     SRX_FLOW_NONE = 0,    /* no flow set: streaming calls fail with SRX_ERR_FLOW */
     SRX_FLOW_TVL1 = 1,    /* built-in duality-based TV-L1 on the GPU             */
-    SRX_FLOW_CALLBACK = 2 /* user plug-in                                        */
+    SRX_FLOW_CALLBACK = 2, /* user plug-in                                       */
+    /* built-in Farneback polynomial-expansion flow on the GPU: the reference's default flow class
+     * (lib/src/btv_l1.cpp:287; parameters and defaults of lib/src/optical_flow.cpp:41-50) */
+    SRX_FLOW_FARNEBACK = 3
 };
 
 /* ---- object life cycle ------------------------------------------------- */
@@ -110,8 +113,9 @@ SRX_API int srx_get_double(srx_handle* h, const char* name, double* value);
  * samples/quality_test/main.cpp:267 */
 SRX_API int srx_set_flow_builtin(srx_handle* h, int kind);
 SRX_API int srx_set_flow_callback(srx_handle* h, srx_flow_fn fn, void* user);
-/* parameters of the built-in flow (tau, lambda, theta, epsilon: double;
- * nscales, warps, iterations: int) */
+/* parameters of the built-in flows.  TV-L1: tau, lambda, theta, epsilon (double); nscales, warps,
+ * iterations (int).  Farneback (names of lib/include/optical_flow.hpp's class Farneback): pyrScale,
+ * polySigma (double); numLevels, winSize, numIters, polyN, flags (int; only flags = 0 is built). */
 SRX_API int srx_flow_set_int(srx_handle* h, const char* name, int value);
 SRX_API int srx_flow_set_double(srx_handle* h, const char* name, double value);
 SRX_API int srx_flow_get_int(srx_handle* h, const char* name, int* value);
@@ -151,10 +155,11 @@ SRX_API int srx_process(srx_handle* h, const srx_image* frames, int n, const srx
 SRX_API int srx_flow_calc(srx_handle* h, const srx_image* frame0, const srx_image* frame1, srx_image* flow1,
                           srx_image* flow2);
 SRX_API int srx_collect_garbage(srx_handle* h);
-/* The built-in TV-L1 flow on two device-resident grey float images (rows x
+/* The built-in flow (Farneback if that is the handle's flow, TV-L1 otherwise) on two
+ * device-resident grey float images (rows x
  * cols, values 0..255) with the handle's flow parameters: flow = rows x cols
  * x 2 interleaved, device.  executed_iterations (optional) receives the
- * number of inner iterations that ran.  This is the standalone flow stage of
+ * number of TV-L1 inner iterations that ran (0 for Farneback).  This is the standalone flow stage of
  * the path (the reference reaches its flow only through
  * DenseOpticalFlow::calc, lib/include/optical_flow.hpp:44). */
 SRX_API int srx_flow_calc_device(srx_handle* h, const float* gray0, const float* gray1, int rows, int cols,

@@ -171,6 +171,29 @@ inline Ptr<DenseOpticalFlow> createOptFlow_DualTVL1()
     return std::make_shared<DualTVL1>();
 }
 
+// The reference's default flow (lib/include/optical_flow.hpp class Farneback; defaults of
+// lib/src/optical_flow.cpp:41-50), here the GPU implementation built into the library.  The public
+// members are applied when the object is handed to setOpticalFlow().
+class Farneback : public DenseOpticalFlow
+{
+  public:
+    double pyrScale = 0.5;
+    int numLevels = 5;
+    int winSize = 13;
+    int numIters = 10;
+    int polyN = 5;
+    double polySigma = 1.1;
+    int flags = 0;
+    void calc(const Mat&, const Mat&, Mat&, Mat*) override
+    {
+        throw Exception(SRX_ERR_STATE, "Farneback runs inside the super-resolution object; use BTV_L1::calcFlow");
+    }
+};
+inline Ptr<DenseOpticalFlow> createOptFlow_Farneback()
+{
+    return std::make_shared<Farneback>();
+}
+
 // The part of cv::Algorithm that the reference's programs use on a Ptr<SuperResolution>
 // (samples/quality_test/main.cpp:261-267): parameters by name.
 class Algorithm
@@ -254,6 +277,17 @@ class BTV_L1 : public SuperResolution
             check(srx_set_flow_builtin(h_, SRX_FLOW_NONE));
         else if (dynamic_cast<DualTVL1*>(flow.get()))
             check(srx_set_flow_builtin(h_, SRX_FLOW_TVL1));
+        else if (const Farneback* fb = dynamic_cast<Farneback*>(flow.get()))
+        {
+            check(srx_set_flow_builtin(h_, SRX_FLOW_FARNEBACK));
+            setFlowParam("pyrScale", fb->pyrScale);
+            setFlowParam("numLevels", fb->numLevels);
+            setFlowParam("winSize", fb->winSize);
+            setFlowParam("numIters", fb->numIters);
+            setFlowParam("polyN", fb->polyN);
+            setFlowParam("polySigma", fb->polySigma);
+            setFlowParam("flags", fb->flags);
+        }
         else
             check(srx_set_flow_callback(h_, &BTV_L1::flow_thunk, this));
     }

@@ -1,4 +1,4 @@
-"""ctypes front end of the CPU oracle (oracle/btvl1_oracle.c, oracle/tvl1_oracle.c).
+"""ctypes front end of the CPU oracle (oracle/btvl1_oracle.c, oracle/tvl1_oracle.c, oracle/farneback_oracle.c).
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by
 bench.py's cpu_baseline leg.  The shipped GPU path never imports this package.
@@ -97,6 +97,10 @@ def _declare(L):
         from . import tvl1 as _tvl1
 
         _tvl1.declare(L)
+    if hasattr(L, "orc_farneback_calc"):
+        from . import farneback as _fb
+
+        _fb.declare(L)
 
 
 def _f32(a) -> np.ndarray:

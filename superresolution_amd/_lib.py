@@ -16,7 +16,7 @@ SRX_OK = 0
 SRX_ERR_INVALID, SRX_ERR_STATE, SRX_ERR_DEVICE, SRX_ERR_SOURCE, SRX_ERR_FLOW = 1, 2, 3, 4, 5
 SRX_8U, SRX_16U, SRX_32F = 0, 2, 5
 SRX_MEM_HOST, SRX_MEM_DEVICE = 0, 1
-SRX_FLOW_NONE, SRX_FLOW_TVL1, SRX_FLOW_CALLBACK = 0, 1, 2
+SRX_FLOW_NONE, SRX_FLOW_TVL1, SRX_FLOW_CALLBACK, SRX_FLOW_FARNEBACK = 0, 1, 2, 3
 SRX_EV_READ, SRX_EV_FLOW, SRX_EV_SOLVE, SRX_EV_OUT = 1, 2, 3, 4
 
 

@@ -75,7 +75,7 @@ class DenseOpticalFlow:
         raise NotImplementedError
 
     def calcFlowDevice(self, gray0, gray1):
-        """Built-in TV-L1 on two CUDA float grey images; returns ((rows, cols, 2) CUDA tensor, executed iterations)."""
+        """Built-in flow (TV-L1, or Farneback when that is set) on two CUDA float grey images; returns ((rows, cols, 2) CUDA tensor, executed iterations)."""
         import torch
 
         rows, cols = gray0.shape
@@ -100,6 +100,22 @@ class CallableFlow(DenseOpticalFlow):
 
 class DualTVL1(DenseOpticalFlow):
     """Marker for the built-in GPU TV-L1 flow; parameters are set through BTV_L1.flowSet()."""
+
+
+class Farneback(DenseOpticalFlow):
+    """The built-in GPU Farneback flow with the parameters of the reference's class Farneback
+    (lib/src/optical_flow.cpp:41-50): pyrScale, numLevels, winSize, numIters, polyN, polySigma, flags.
+    Attributes set on this object are applied when it is handed to BTV_L1.setOpticalFlow()."""
+
+    _NAMES = ("pyrScale", "numLevels", "winSize", "numIters", "polyN", "polySigma", "flags")
+
+    def __init__(self, **kw):
+        self.pyrScale, self.numLevels, self.winSize, self.numIters = 0.5, 5, 13, 10
+        self.polyN, self.polySigma, self.flags = 5, 1.1, 0
+        for k, v in kw.items():
+            if k not in self._NAMES:
+                raise TypeError("unknown Farneback parameter: " + k)
+            setattr(self, k, v)
 
 
 def _view(im: L.SrxImage):
@@ -176,6 +192,13 @@ class BTV_L1:
         if isinstance(flow, DualTVL1):
             self._flow = flow
             L.check(self._lib.srx_set_flow_builtin(self._h, L.SRX_FLOW_TVL1))
+            return
+        if isinstance(flow, Farneback):
+            self._flow = flow
+            L.check(self._lib.srx_set_flow_builtin(self._h, L.SRX_FLOW_FARNEBACK))
+            for n in Farneback._NAMES:
+                v = getattr(flow, n)
+                self.flowSet(n, float(v) if n in ("pyrScale", "polySigma") else int(v))
             return
         if callable(flow) and not isinstance(flow, DenseOpticalFlow):
             flow = CallableFlow(flow)
@@ -298,7 +321,7 @@ class BTV_L1:
         return fl
 
     def calcFlowDevice(self, gray0, gray1):
-        """Built-in TV-L1 on two CUDA float grey images; returns ((rows, cols, 2) CUDA tensor, executed iterations)."""
+        """Built-in flow (TV-L1, or Farneback when that is set) on two CUDA float grey images; returns ((rows, cols, 2) CUDA tensor, executed iterations)."""
         import torch
 
         rows, cols = gray0.shape

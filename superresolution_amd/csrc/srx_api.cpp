@@ -3,6 +3,7 @@
 // stage-level entry points.
 #include "srx_host.h"
 #include "srx_tvl1.h"
+#include "srx_farneback.h"
 
 #include <algorithm>
 #include <cstring>
@@ -75,6 +76,15 @@ struct srx_handle
     void* flow_user = nullptr;
     Tvl1Params flow_params;
     Tvl1 tvl1;
+    FarnebackParams fb_params;
+    Farneback farneback;
+    // the built-in flow of this handle on two frames, on the given stream
+    int builtin_flow(const srx_image& f0, const srx_image& f1, float* dst, hipStream_t st)
+    {
+        if (flow_kind == SRX_FLOW_FARNEBACK)
+            return farneback.calc_images(f0, f1, fb_params, dst, st);
+        return tvl1.calc_images(f0, f1, flow_params, dst, nullptr, st);
+    }
 
     // frame source
     srx_next_frame_fn next = nullptr;
@@ -175,11 +185,11 @@ int srx_handle::calc_flow(const srx_image& f0, const srx_image& f1, float* dst)
         (void)bytes;
         return copy_to_device(fl, dst, stream);
     }
-    if (flow_kind == SRX_FLOW_TVL1)
+    if (flow_kind == SRX_FLOW_TVL1 || flow_kind == SRX_FLOW_FARNEBACK)
     {
         if (dry)
             return SRX_OK;
-        return tvl1.calc_images(f0, f1, flow_params, dst, nullptr, stream);
+        return builtin_flow(f0, f1, dst, stream);
     }
     set_error("no optical flow set (srx_set_flow_builtin / srx_set_flow_callback)");
     return SRX_ERR_FLOW;
@@ -305,7 +315,7 @@ int srx_handle::read_ahead()
         if (int rc = look_flow.reserve((size_t)rows * cols * 2 * sizeof(float)))
             return rc;
         SRX_HIP(hipStreamWaitEvent(stream2, prev_ready, 0)); // prevFrame was written on the main stream
-        if (int rc = tvl1.calc_images(prev_hdr, look_hdr, flow_params, look_flow.as<float>(), nullptr, stream2))
+        if (int rc = builtin_flow(prev_hdr, look_hdr, look_flow.as<float>(), stream2))
             return rc;
         SRX_HIP(hipStreamSynchronize(stream2));
     }
@@ -395,7 +405,7 @@ int srx_handle::process_impl(srx_image* out, bool* produced)
     if (got)
         if (int rc = add_new_frame(frame, ahead))
             return rc;
-    const bool look = readAhead && flow_kind == SRX_FLOW_TVL1 && got && !look_end;
+    const bool look = readAhead && (flow_kind == SRX_FLOW_TVL1 || flow_kind == SRX_FLOW_FARNEBACK) && got && !look_end;
     if (look && !dry && stream2)
         SRX_HIP(hipEventRecord(prev_ready, stream));
     if (procPos < storePos)
@@ -664,7 +674,7 @@ SRX_API int srx_get_double(srx_handle* h, const char* name, double* value)
 SRX_API int srx_set_flow_builtin(srx_handle* h, int kind)
 {
     SRX_NEED(h);
-    if (kind != SRX_FLOW_NONE && kind != SRX_FLOW_TVL1)
+    if (kind != SRX_FLOW_NONE && kind != SRX_FLOW_TVL1 && kind != SRX_FLOW_FARNEBACK)
     {
         set_error("unknown built-in flow");
         return SRX_ERR_INVALID;
@@ -692,21 +702,35 @@ SRX_API int srx_set_flow_callback(srx_handle* h, srx_flow_fn fn, void* user)
 SRX_API int srx_flow_set_int(srx_handle* h, const char* name, int value)
 {
     SRX_NEED(h);
+    bool known = false;
+    if (int rc = farneback_set_int(h->fb_params, name ? name : "", value, &known))
+        return rc;
+    if (known)
+        return SRX_OK;
     return tvl1_set_int(h->flow_params, name ? name : "", value);
 }
 SRX_API int srx_flow_set_double(srx_handle* h, const char* name, double value)
 {
     SRX_NEED(h);
+    bool known = false;
+    if (int rc = farneback_set_double(h->fb_params, name ? name : "", value, &known))
+        return rc;
+    if (known)
+        return SRX_OK;
     return tvl1_set_double(h->flow_params, name ? name : "", value);
 }
 SRX_API int srx_flow_get_int(srx_handle* h, const char* name, int* value)
 {
     SRX_NEED(h);
+    if (value && farneback_get_int(h->fb_params, name ? name : "", value))
+        return SRX_OK;
     return tvl1_get_int(h->flow_params, name ? name : "", value);
 }
 SRX_API int srx_flow_get_double(srx_handle* h, const char* name, double* value)
 {
     SRX_NEED(h);
+    if (value && farneback_get_double(h->fb_params, name ? name : "", value))
+        return SRX_OK;
     return tvl1_get_double(h->flow_params, name ? name : "", value);
 }
 
@@ -982,7 +1006,14 @@ SRX_API int srx_flow_calc_device(srx_handle* h, const float* gray0, const float*
     }
     if (int rc = h->set_device())
         return rc;
-    if (int rc = h->tvl1.calc_gray(gray0, gray1, rows, cols, h->flow_params, flow, executed_iterations, h->stream))
+    if (h->flow_kind == SRX_FLOW_FARNEBACK)
+    {
+        if (int rc = h->farneback.calc_gray(gray0, gray1, rows, cols, h->fb_params, flow, h->stream))
+            return rc;
+        if (executed_iterations)
+            *executed_iterations = 0;
+    }
+    else if (int rc = h->tvl1.calc_gray(gray0, gray1, rows, cols, h->flow_params, flow, executed_iterations, h->stream))
         return rc;
     SRX_HIP(hipStreamSynchronize(h->stream));
     return SRX_OK;
@@ -997,6 +1028,7 @@ SRX_API int srx_collect_garbage(srx_handle* h)
         return rc;
     SRX_HIP(hipStreamSynchronize(h->stream));
     h->tvl1.release();
+    h->farneback.release();
     h->staging.release();
     h->flow_dev.release();
     h->batch_out.release();

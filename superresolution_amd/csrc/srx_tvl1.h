@@ -41,6 +41,10 @@ class Tvl1
     std::shared_ptr<Impl> impl_;
 };
 
+// frame (device, dense rows) -> 8-bit grey as float, the way convertToType(frame, CV_8U, 1) reduces it
+// (lib/src/input_array_utility.cpp:77-124); depth: SRX_8U / SRX_16U / SRX_32F
+int launch_to_gray(const void* raw, size_t px, int ch, int depth, float* gray, hipStream_t st);
+
 // interleaved (u,v) -> two planes
 int launch_split2(const float* uv, size_t count, float* u, float* v, hipStream_t st);
 

@@ -589,6 +589,15 @@ constexpr int kPollStride = 32; // inner iterations enqueued between two looks a
 
 } // namespace
 
+// frame (device, dense) -> 8-bit grey as float; depth: SRX_8U / SRX_16U / SRX_32F
+int launch_to_gray(const void* raw, size_t px, int ch, int depth, float* gray, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_to_gray, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, st, raw, px, ch,
+                       depth == SRX_32F ? 1 : (depth == SRX_16U ? 2 : 0), gray);
+    SRX_LAUNCH_CHECK("to_gray");
+    return SRX_OK;
+}
+
 struct Tvl1::Impl
 {
     struct Level

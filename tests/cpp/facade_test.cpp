@@ -145,6 +145,33 @@ int main()
     while (!ahead.nextFrame().empty())
         ++more;
     REQUIRE(more == 6);
+
+    // the reference's default flow class as a built-in: members travel with setOpticalFlow, bad values throw
+    {
+        BTV_L1 fbsr(-1);
+        auto fb = std::make_shared<Farneback>();
+        REQUIRE(fb->pyrScale == 0.5 && fb->numLevels == 5 && fb->winSize == 13 && fb->numIters == 10 &&
+                fb->polyN == 5 && fb->polySigma == 1.1 && fb->flags == 0); // lib/src/optical_flow.cpp:41-50
+        fb->winSize = 9;
+        fbsr.set("opticalFlow", Ptr<DenseOpticalFlow>(fb));
+        fbsr.set("temporalAreaRadius", 1);
+        fbsr.setFrameSource(std::make_shared<Source16>(4));
+        int outs = 0;
+        while (!fbsr.nextFrame().empty())
+            ++outs;
+        REQUIRE(outs == 4);
+        fb->flags = 256; // the Gaussian window is not built
+        bool threw = false;
+        try
+        {
+            fbsr.setOpticalFlow(fb);
+        }
+        catch (const Exception&)
+        {
+            threw = true;
+        }
+        REQUIRE(threw);
+    }
     std::puts("facade ok");
     return 0;
 }
