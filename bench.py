@@ -50,8 +50,9 @@ def parse():
     ap.add_argument("--scale", type=int, default=4)
     ap.add_argument("--radius", type=int, default=4)
     ap.add_argument("--iterations", type=int, default=180)
-    ap.add_argument("--flow", choices=["synthetic", "tvl1"], default="tvl1",
-                    help="motion stage: exact synthetic motion resident in HBM, or the built-in TV-L1 flow")
+    ap.add_argument("--flow", choices=["synthetic", "tvl1", "farneback"], default="tvl1",
+                    help="motion stage: exact synthetic motion resident in HBM, the built-in TV-L1 flow, or the "
+                         "built-in Farneback flow (the reference's default flow class)")
     ap.add_argument("--no-read-ahead", action="store_true",
                     help="read each frame in the call that needs it, as the reference does (default: the next "
                          "frame is read one call early and its TV-L1 flow runs beside the current solve)")
@@ -177,7 +178,7 @@ def main():
     # Calls: one set-up call (ring warm-up: 2r+2 reads), then W warm-up and K timed steady-state steps with one
     # read, one flow and one solve each.  The solve of a call runs r+1 frames ahead of the output it returns, so
     # a span of W + K + r + 2 owned frames keeps every timed solve inside the span with a full window.
-    read_ahead = args.flow == "tvl1" and not args.no_read_ahead
+    read_ahead = args.flow != "synthetic" and not args.no_read_ahead
     n_own = args.warmup + args.steps + r + 2 + (1 if read_ahead else 0)  # read-ahead pulls one frame more
     total = n_own * world
     a = rank * n_own
@@ -216,6 +217,8 @@ def main():
     sr.set("readAhead", 1 if read_ahead else 0)
     if args.flow == "tvl1":
         sr.setOpticalFlow(api.DualTVL1())
+    elif args.flow == "farneback":
+        sr.setOpticalFlow(api.Farneback())
     else:
         counter = {"i": 0}
 
@@ -300,7 +303,8 @@ def main():
                 "workload": f"{'configs[3]' if default_workload else 'other configuration'}: {args.cols}x{args.rows} {'RGB' if args.channels == 3 else 'gray'} -> "
                             f"{args.cols * s}x{args.rows * s}, {s}x BTV-L1, {args.iterations} iterations, "
                             f"temporalAreaRadius {r} (window {K}), streaming nextFrame(), motion: "
-                            + ("built-in TV-L1 flow" if args.flow == "tvl1" else "exact synthetic flow resident in HBM"),
+                            + {"tvl1": "built-in TV-L1 flow", "farneback": "built-in Farneback flow"}.get(
+                                args.flow, "exact synthetic flow resident in HBM"),
                 "frames_per_gpu": args.steps,
                 "io": "host frames in, host frames out (PCIe inclusive)" if args.host_io else "frames resident in HBM",
                 "read_ahead": read_ahead,

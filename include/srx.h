@@ -77,11 +77,12 @@ typedef int (*srx_flow_fn)(void* user, const srx_image* frame0, const srx_image*
 
 enum
 {
-    SRX_FLOW_NONE = 0,    /* no flow set: streaming calls fail with SRX_ERR_FLOW */
+    SRX_FLOW_NONE = 0,    /* flow removed: streaming calls fail with SRX_ERR_FLOW */
     SRX_FLOW_TVL1 = 1,    /* built-in duality-based TV-L1 on the GPU             */
     SRX_FLOW_CALLBACK = 2, /* user plug-in                                       */
     /* built-in Farneback polynomial-expansion flow on the GPU: the reference's default flow class
-     * (lib/src/btv_l1.cpp:287; parameters and defaults of lib/src/optical_flow.cpp:41-50) */
+     * (lib/src/btv_l1.cpp:287; parameters and defaults of lib/src/optical_flow.cpp:41-50) and the flow
+     * of a new handle */
     SRX_FLOW_FARNEBACK = 3
 };
 

@@ -13,6 +13,7 @@ a = ap.parse_args()
 cams = synth.camera_path(2, seed=5)
 f = [synth.ground_truth_frame(c, a.rows, a.cols, 1, 5, "cuda")[:, :, 0].float().contiguous() for c in cams]
 sr = api.BTV_L1()
+sr.setOpticalFlow(api.DualTVL1())
 sr.flowSet("epsilon", a.eps)
 for _ in range(a.reps):
     torch.cuda.synchronize()

@@ -8,6 +8,7 @@ rows, cols, ch, s, n = 540, 960, 3, 4, 5
 lr, flows, _ = synth.make_sequence(n, rows, cols, ch, s, seed=1234, device="cuda")
 sr = api.BTV_L1()
 sr.setOpticalFlow(api.DualTVL1())
+sr.setOpticalFlow(api.DualTVL1())
 gray = [f.to(torch.float32).mean(dim=2) for f in lr]
 
 

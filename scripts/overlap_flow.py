@@ -9,6 +9,7 @@ lr, flows, _ = synth.make_sequence(K, rows, cols, ch, scale, seed=1234, device="
 y = [f.to(torch.float32) for f in lr]
 gray = [f.to(torch.float32).mean(dim=2).contiguous() for f in lr]
 solver, flower = api.BTV_L1(), api.BTV_L1()
+flower.setOpticalFlow(api.DualTVL1())
 solver.set("scale", scale); solver.set("iterations", iters)
 flower.setOpticalFlow(api.DualTVL1())
 

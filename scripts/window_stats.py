@@ -11,6 +11,7 @@ lr, flows, _ = synth.make_sequence(F0 + n, rows, cols, ch, s, seed=1234, device=
 lr, flows = lr[F0:], flows[F0:]
 sr = api.BTV_L1()
 sr.setOpticalFlow(api.DualTVL1())
+sr.setOpticalFlow(api.DualTVL1())
 gray = [f.to(torch.float32).mean(dim=2) for f in lr]
 H, W = rows * s, cols * s
 

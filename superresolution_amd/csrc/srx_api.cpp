@@ -71,7 +71,7 @@ struct srx_handle
     Params p;
 
     // optical flow plug-in
-    int flow_kind = SRX_FLOW_NONE;
+    int flow_kind = SRX_FLOW_FARNEBACK; // opticalFlow = new Farneback, lib/src/btv_l1.cpp:287
     srx_flow_fn flow_fn = nullptr;
     void* flow_user = nullptr;
     Tvl1Params flow_params;

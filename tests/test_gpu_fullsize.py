@@ -133,6 +133,7 @@ def test_tvl1_at_cfg3_size():
     cam = synth.camera_path(1, seed=9)[0]
     f0 = synth.ground_truth_frame(cam, rows, cols, 1, 9, "cuda")[:, :, 0].float().contiguous()
     sr = api.BTV_L1()
+    sr.setOpticalFlow(api.DualTVL1())
     flow, n = sr.calcFlowDevice(f0, f0)
     assert torch.count_nonzero(flow) == 0
     # a frame shifted by (+3, -2) pixels: flow(f0 -> f1) = (+3, -2) away from the border

@@ -181,9 +181,18 @@ def test_frame_type_change_is_rejected():
             pass
 
 
-def test_missing_flow_is_an_error():
+def test_default_flow_is_farneback_and_a_removed_flow_is_an_error():
+    """opticalFlow = new Farneback (lib/src/btv_l1.cpp:287): a new object streams without a flow being set."""
     sr = api.BTV_L1(-1)
     sr.set("temporalAreaRadius", 1)
+    sr.set("traceEvents", 1)
+    sr.setFrameSource(ostream.ListFrameSource([np.zeros((6, 8), np.uint8)] * 4))
+    n = 0
+    while sr.nextFrame() is not None:
+        n += 1
+    assert n == 4
+    L.check(sr._lib.srx_set_flow_builtin(sr._h, L.SRX_FLOW_NONE))
+    sr.reset()
     sr.setFrameSource(ostream.ListFrameSource([np.zeros((6, 8), np.uint8)] * 4))
     with pytest.raises(L.SrxError) as e:
         sr.nextFrame()

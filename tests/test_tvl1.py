@@ -94,6 +94,7 @@ def test_gpu_flow_device_entry_and_iteration_count():
     ga, gb = tvl1.to_gray(a), tvl1.to_gray(b)
     ref, n_ref = tvl1.calc_gray(ga, gb)
     sr = api.BTV_L1()
+    sr.setOpticalFlow(api.DualTVL1())
     flow, n = sr.calcFlowDevice(torch.from_numpy(ga).cuda(), torch.from_numpy(gb).cuda())
     assert n == n_ref
     assert np.array_equal(flow.cpu().numpy(), ref)
