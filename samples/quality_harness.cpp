@@ -177,6 +177,14 @@ int arg_int(int argc, char** argv, const char* name, int dflt)
             return std::atoi(argv[i + 1]);
     return dflt;
 }
+const char* arg_str(int argc, char** argv, const char* name, const char* dflt)
+{
+    for (int i = 1; i + 1 < argc; ++i)
+        if (std::strcmp(argv[i], name) == 0)
+            return argv[i + 1];
+    return dflt;
+}
+
 bool arg_flag(int argc, char** argv, const char* name)
 {
     for (int i = 1; i < argc; ++i)
@@ -194,6 +202,13 @@ int main(int argc, char** argv)
     const int rows = arg_int(argc, argv, "--rows", 240) / scale * scale, cols = arg_int(argc, argv, "--cols", 320) / scale * scale;
     const int ch = arg_int(argc, argv, "--channels", 1), frames = arg_int(argc, argv, "--frames", 12);
     const bool noise = arg_flag(argc, argv, "--noise");
+    // --opt-flow farneback | tvl1; farneback is the default of samples/quality_test/main.cpp:209
+    const std::string optFlow = arg_str(argc, argv, "--opt-flow", "farneback");
+    if (optFlow != "farneback" && optFlow != "tvl1")
+    {
+        std::fprintf(stderr, "Incorrect Optical Flow algorithm - %s\n", optFlow.c_str());
+        return 1;
+    }
     try
     {
         Ptr<SuperResolution> superRes = createSuperResolution_BTVL1(0);
@@ -201,7 +216,7 @@ int main(int argc, char** argv)
         superRes->set("scale", scale);
         superRes->set("iterations", iterations);
         superRes->set("temporalAreaRadius", temporal);
-        superRes->setOpticalFlow(createOptFlow_DualTVL1());
+        superRes->setOpticalFlow(optFlow == "tvl1" ? createOptFlow_DualTVL1() : createOptFlow_Farneback());
 
         Ptr<IFrameSource> gold(new GoldSource(rows, cols, ch, frames));
         Ptr<IFrameSource> lowRes(new DegradedSource(Ptr<IFrameSource>(new GoldSource(rows, cols, ch, frames)), scale, noise));
@@ -210,8 +225,8 @@ int main(int argc, char** argv)
 
         std::printf("Input             : synthetic %dx%d, %d channel(s), %d frames%s\n", cols, rows, ch, frames,
                     noise ? ", noise" : "");
-        std::printf("Scale factor      : %d\nIterations        : %d\nFrames to process : %d\nOptical Flow      : tvl1\n\n",
-                    scale, iterations, 2 * temporal + 1);
+        std::printf("Scale factor      : %d\nIterations        : %d\nFrames to process : %d\nOptical Flow      : %s\n\n",
+                    scale, iterations, 2 * temporal + 1, optFlow.c_str());
         std::printf("-----------------------------------------------------------------\n");
         std::printf("|   Ind    |  SuperRes PSNR / MSSIM  |   BiCubic PSNR / MSSIM   |\n");
         std::printf("|----------|-------------------------|--------------------------|\n");

@@ -79,3 +79,36 @@ def test_gpu_reproduces_golden_stream():
     for ref in z["outs"]:
         assert np.array_equal(np.asarray(sr.nextFrame()), ref)
     assert sr.nextFrame() is None
+
+
+def _flow_case():
+    from oracle import tvl1
+
+    z = np.load(os.path.join(GOLD, "flow_pair_rgb.npz"))
+    n, w, it = (int(v) for v in z["tvl1_params"])
+    return z, tvl1.Tvl1Params(nscales=n, warps=w, iterations=it), dict(nscales=n, warps=w, iterations=it)
+
+
+def test_oracle_reproduces_golden_flows():
+    from oracle import farneback, tvl1
+
+    z, tp, _ = _flow_case()
+    a, b = z["frames"]
+    assert np.array_equal(tvl1.calc(a, b, tp), z["tvl1"])
+    assert np.array_equal(farneback.calc(a, b), z["farneback"])
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden_flows():
+    from superresolution_amd import api
+
+    z, _, kw = _flow_case()
+    a, b = z["frames"]
+    sr = api.BTV_L1()
+    assert np.array_equal(sr.calcFlow(a, b), z["farneback"])  # the flow of a new object (lib/src/btv_l1.cpp:287)
+    sr.setOpticalFlow(api.DualTVL1())
+    for k, v in kw.items():
+        sr.flowSet(k, v)
+    assert np.array_equal(sr.calcFlow(a, b), z["tvl1"])
+    sr.setOpticalFlow(api.Farneback())
+    assert np.array_equal(sr.calcFlow(a, b), z["farneback"])

@@ -12,13 +12,15 @@ EXE = os.path.join(ROOT, "samples", "bin", "quality_harness")
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("flow", ["farneback", "tvl1"])
 @pytest.mark.parametrize("channels", [1, 3])
-def test_super_resolution_beats_bicubic(channels):
+def test_super_resolution_beats_bicubic(channels, flow):
     assert os.path.exists(EXE), "samples/bin/quality_harness is missing: run __graft_entry__.build()"
     r = subprocess.run([EXE, "--rows", "128", "--cols", "160", "--frames", "9", "--temporal", "2", "--iterations",
-                        "60", "--channels", str(channels)], capture_output=True, text=True, timeout=100)
+                        "60", "--channels", str(channels), "--opt-flow", flow], capture_output=True, text=True, timeout=100)
     assert r.returncode == 0, r.stdout + r.stderr
     rows = re.findall(r"\|\s+\[\s*(\d+)\]\s+\|\s+([\d.]+) / ([\d.]+)\s+\|\s+([\d.]+) / ([\d.]+)", r.stdout)
+    assert "Optical Flow      : " + flow in r.stdout
     assert len(rows) == 9                     # one output per input frame
     sr = sum(float(x[1]) for x in rows) / len(rows)
     bc = sum(float(x[3]) for x in rows) / len(rows)
