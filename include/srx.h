@@ -116,7 +116,8 @@ SRX_API int srx_set_flow_builtin(srx_handle* h, int kind);
 SRX_API int srx_set_flow_callback(srx_handle* h, srx_flow_fn fn, void* user);
 /* parameters of the built-in flows.  TV-L1: tau, lambda, theta, epsilon (double); nscales, warps,
  * iterations (int).  Farneback (names of lib/include/optical_flow.hpp's class Farneback): pyrScale,
- * polySigma (double); numLevels, winSize, numIters, polyN, flags (int; only flags = 0 is built). */
+ * polySigma (double); numLevels, winSize, numIters, polyN, flags (int; 0 = box window, 256 = Gaussian
+ * window as OPTFLOW_FARNEBACK_GAUSSIAN; an initial flow, flag 4, is not built). */
 SRX_API int srx_flow_set_int(srx_handle* h, const char* name, int value);
 SRX_API int srx_flow_set_double(srx_handle* h, const char* name, double value);
 SRX_API int srx_flow_get_int(srx_handle* h, const char* name, int* value);

@@ -30,6 +30,7 @@ def declare(L):
     L.orc_farneback_poly_exp.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _dp, _fp]
     L.orc_farneback_update_matrices.argtypes = [_fp, _fp, _fp, C.c_int, C.c_int, _fp]
     L.orc_farneback_update_flow.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp]
+    L.orc_farneback_update_flow_gaussian.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp]
     L.orc_farneback_levels.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int]
     L.orc_farneback_levels.restype = C.c_int
     L.orc_farneback_calc.argtypes = [_fp, _fp, C.c_int, C.c_int, C.POINTER(FarnebackParams), _fp]
@@ -81,10 +82,11 @@ def update_matrices(R0, R1, flow) -> np.ndarray:
     return M
 
 
-def update_flow(M, win: int) -> np.ndarray:
+def update_flow(M, win: int, gaussian: bool = False) -> np.ndarray:
     m = _f32(M)
     flow = np.empty(m.shape[:2] + (2,), np.float32)
-    _lib().orc_farneback_update_flow(_p(m), m.shape[0], m.shape[1], win, _p(flow))
+    fn = _lib().orc_farneback_update_flow_gaussian if gaussian else _lib().orc_farneback_update_flow
+    fn(_p(m), m.shape[0], m.shape[1], win, _p(flow))
     return flow
 
 

@@ -34,7 +34,10 @@
  *              replicated borders, summed in double (rows top to bottom, then columns left to
  *              right; OpenCV keeps running sums, which can differ in the last bit of a double),
  *              2x2 solve with 1e-3 added to the determinant; matrices recomputed from the new
- *              flow after every iteration but the last.
+ *              flow after every iteration but the last.  With flags = 256
+ *              (OPTFLOW_FARNEBACK_GAUSSIAN) the window is a winSize-tap Gaussian of sigma
+ *              0.3 (winSize / 2) instead of the box: float, vertical pass then horizontal pass, centre tap plus
+ *              symmetric pairs, replicated borders.  Flag 4 (initial flow) is not restated.
  */
 #include <float.h>
 #include <math.h>
@@ -350,6 +353,58 @@ ORC_API void orc_farneback_update_flow(const float* M, int rows, int cols, int w
     free(vs);
 }
 
+/* The same with a Gaussian window (OPTFLOW_FARNEBACK_GAUSSIAN). */
+ORC_API void orc_farneback_update_flow_gaussian(const float* M, int rows, int cols, int win, float* flow)
+{
+    const int m = win / 2;
+    const double sigma = m * 0.3;
+    float* kernel = (float*)malloc(sizeof(float) * (size_t)(m + 1));
+    double s = 1;
+    kernel[0] = (float)s;
+    for (int i = 1; i <= m; ++i)
+    {
+        const float t = (float)exp(-i * i / (2 * sigma * sigma));
+        kernel[i] = t;
+        s += t * 2;
+    }
+    s = 1. / s;
+    for (int i = 0; i <= m; ++i)
+        kernel[i] = (float)(kernel[i] * s);
+    float* vs = (float*)malloc(sizeof(float) * (size_t)rows * cols * 5);
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols * 5; ++x)
+        {
+            float s0 = M[(size_t)y * cols * 5 + x] * kernel[0];
+            for (int i = 1; i <= m; ++i)
+                s0 += (M[(size_t)clampi(y + i, 0, rows - 1) * cols * 5 + x] +
+                       M[(size_t)clampi(y - i, 0, rows - 1) * cols * 5 + x]) *
+                      kernel[i];
+            vs[(size_t)y * cols * 5 + x] = s0;
+        }
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < rows; ++y)
+    {
+        const float* v = vs + (size_t)y * cols * 5;
+        for (int x = 0; x < cols; ++x)
+        {
+            float h[5];
+            for (int e = 0; e < 5; ++e)
+            {
+                float sum = v[x * 5 + e] * kernel[0];
+                for (int i = 1; i <= m; ++i)
+                    sum += kernel[i] * (v[clampi(x - i, 0, cols - 1) * 5 + e] + v[clampi(x + i, 0, cols - 1) * 5 + e]);
+                h[e] = sum;
+            }
+            const double g11 = h[0], g12 = h[1], g22 = h[2], h1 = h[3], h2 = h[4];
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            flow[((size_t)y * cols + x) * 2] = (float)((g11 * h2 - g12 * h1) * idet);
+            flow[((size_t)y * cols + x) * 2 + 1] = (float)((g22 * h1 - g12 * h2) * idet);
+        }
+    }
+    free(vs), free(kernel);
+}
+
 /* number of pyramid levels below the full size that are used (calcOpticalFlowFarneback's
  * min_size rule) */
 ORC_API int orc_farneback_levels(int rows, int cols, double pyr_scale, int levels)
@@ -370,7 +425,7 @@ ORC_API int orc_farneback_calc(const float* I0, const float* I1, int rows, int c
                                float* flow_out)
 {
     if (rows < 1 || cols < 1 || !(p->pyrScale > 0 && p->pyrScale < 1) || p->winSize < 1 || p->numIters < 0 ||
-        p->polyN < 1 || p->polyN > FB_MAX_POLY || p->flags != 0)
+        p->polyN < 1 || p->polyN > FB_MAX_POLY || (p->flags != 0 && p->flags != 256))
         return -1;
     const int levels = orc_farneback_levels(rows, cols, p->pyrScale, p->numLevels);
     float g[FB_MAX_POLY + 1], xg[FB_MAX_POLY + 1], xxg[FB_MAX_POLY + 1];
@@ -423,7 +478,10 @@ ORC_API int orc_farneback_calc(const float* I0, const float* I1, int rows, int c
         orc_farneback_update_matrices(R[0], R[1], flow, height, width, M);
         for (int i = 0; i < p->numIters; ++i)
         {
-            orc_farneback_update_flow(M, height, width, p->winSize, flow);
+            if (p->flags & 256)
+                orc_farneback_update_flow_gaussian(M, height, width, p->winSize, flow);
+            else
+                orc_farneback_update_flow(M, height, width, p->winSize, flow);
             if (i < p->numIters - 1)
                 orc_farneback_update_matrices(R[0], R[1], flow, height, width, M);
         }

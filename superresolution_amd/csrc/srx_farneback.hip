@@ -338,6 +338,68 @@ __global__ void k_fb_box_solve(const double* __restrict__ vs, int rows, int cols
         make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
 }
 
+// Gaussian window (OPTFLOW_FARNEBACK_GAUSSIAN): half kernel of the window, float
+struct FbWindow
+{
+    float k[128]; // winSize <= 255
+    int m;
+};
+
+// window pass down the rows: centre tap plus symmetric pairs, replicated rows; one thread per entry
+__global__ void k_fb_gauss_rows(const float* __restrict__ M, int rows, int cols5, FbWindow w, float* __restrict__ vs)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= cols5 || y >= rows)
+        return;
+    float s0 = M[(size_t)y * cols5 + x] * w.k[0];
+    for (int i = 1; i <= w.m; ++i)
+        s0 += (M[(size_t)clampi(y + i, 0, rows - 1) * cols5 + x] + M[(size_t)clampi(y - i, 0, rows - 1) * cols5 + x]) *
+              w.k[i];
+    vs[(size_t)y * cols5 + x] = s0;
+}
+
+// window pass along the columns and the 2x2 solve
+__global__ void k_fb_gauss_solve(const float* __restrict__ vs, int rows, int cols, FbWindow w, float* __restrict__ flow)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= cols || y >= rows)
+        return;
+    const float* v = vs + (size_t)y * cols * 5;
+    float h[5];
+#pragma unroll
+    for (int e = 0; e < 5; ++e)
+    {
+        float sum = v[x * 5 + e] * w.k[0];
+        for (int i = 1; i <= w.m; ++i)
+            sum += w.k[i] * (v[clampi(x - i, 0, cols - 1) * 5 + e] + v[clampi(x + i, 0, cols - 1) * 5 + e]);
+        h[e] = sum;
+    }
+    const double g11 = h[0], g12 = h[1], g22 = h[2], h1 = h[3], h2 = h[4];
+    const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+    ((float2*)flow)[(size_t)y * cols + x] =
+        make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
+}
+
+void window_setup(int win, FbWindow& w)
+{
+    const int m = win / 2;
+    const double sigma = m * 0.3;
+    double s = 1;
+    w.k[0] = (float)s;
+    for (int i = 1; i <= m; ++i)
+    {
+        const float t = (float)std::exp(-i * i / (2 * sigma * sigma));
+        w.k[i] = t;
+        s += t * 2;
+    }
+    s = 1. / s;
+    for (int i = 0; i <= m; ++i)
+        w.k[i] = (float)(w.k[i] * s);
+    w.m = m;
+}
+
+constexpr int kFlagGaussian = 256; // OPTFLOW_FARNEBACK_GAUSSIAN
+
 inline dim3 grid2(int cols, int rows, dim3 b)
 {
     return dim3((cols + b.x - 1) / b.x, (rows + b.y - 1) / b.y);
@@ -359,8 +421,8 @@ int check_params(const FarnebackParams& p)
         return fb_bad("Farneback: numLevels >= 0, 1 <= winSize <= 255, numIters >= 0 required");
     if (p.polyN < 1 || p.polyN > kMaxPoly)
         return fb_bad("Farneback: polyN must lie in 1..16");
-    if (p.flags != 0)
-        return fb_bad("Farneback: only flags = 0 (box window, no initial flow) is built");
+    if (p.flags != 0 && p.flags != kFlagGaussian)
+        return fb_bad("Farneback: flags must be 0 (box window) or 256 (Gaussian window); an initial flow is not built");
     return SRX_OK;
 }
 
@@ -565,11 +627,23 @@ int Farneback::calc_gray(const float* I0, const float* I1, int rows, int cols, c
                            width, m.M.as<float>());
         const int half = p.winSize / 2;
         const double norm = 1. / ((double)p.winSize * p.winSize);
+        FbWindow win;
+        if (p.flags & kFlagGaussian)
+            window_setup(p.winSize, win);
         for (int i = 0; i < p.numIters; ++i)
         {
-            hipLaunchKernelGGL(k_fb_box_rows, grid2(width * 5, height, b), b, 0, st, m.M.as<float>(), height,
-                               width * 5, half, m.vs.as<double>());
-            hipLaunchKernelGGL(k_fb_box_solve, g, b, 0, st, m.vs.as<double>(), height, width, half, norm, flow);
+            if (p.flags & kFlagGaussian)
+            {
+                hipLaunchKernelGGL(k_fb_gauss_rows, grid2(width * 5, height, b), b, 0, st, m.M.as<float>(), height,
+                                   width * 5, win, m.vs.as<float>());
+                hipLaunchKernelGGL(k_fb_gauss_solve, g, b, 0, st, m.vs.as<float>(), height, width, win, flow);
+            }
+            else
+            {
+                hipLaunchKernelGGL(k_fb_box_rows, grid2(width * 5, height, b), b, 0, st, m.M.as<float>(), height,
+                                   width * 5, half, m.vs.as<double>());
+                hipLaunchKernelGGL(k_fb_box_solve, g, b, 0, st, m.vs.as<double>(), height, width, half, norm, flow);
+            }
             if (i < p.numIters - 1)
                 hipLaunchKernelGGL(k_fb_update_matrices, g, b, 0, st, m.R[0].as<float>(), m.R[1].as<float>(), flow,
                                    height, width, m.M.as<float>());

@@ -160,7 +160,7 @@ int main()
         while (!fbsr.nextFrame().empty())
             ++outs;
         REQUIRE(outs == 4);
-        fb->flags = 256; // the Gaussian window is not built
+        fb->flags = 4; // an initial flow is not built
         bool threw = false;
         try
         {

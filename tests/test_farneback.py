@@ -83,6 +83,33 @@ def test_update_flow_is_a_box_mean_and_a_2x2_solve():
     assert np.allclose(fl[..., 1], v * det / (det + 1e-3), atol=1e-6)
 
 
+def test_gaussian_window_weights_sum_to_one_and_solve_the_same_system():
+    rows, cols, win = 20, 24, 7
+    M = np.zeros((rows, cols, 5), np.float32)
+    M[..., 0], M[..., 1], M[..., 2] = 2.0, 0.5, 3.0
+    u, v = 0.75, -1.25
+    M[..., 3] = 2.0 * v + 0.5 * u
+    M[..., 4] = 0.5 * v + 3.0 * u
+    fl = fb.update_flow(M, win, gaussian=True)
+    det = 2.0 * 3.0 - 0.25
+    assert np.allclose(fl[..., 0], u * det / (det + 1e-3), atol=1e-5)
+    assert np.allclose(fl[..., 1], v * det / (det + 1e-3), atol=1e-5)
+    # an impulse in h spreads as the outer product of the window's taps
+    M[...] = 0
+    M[..., 0] = M[..., 2] = 1.0
+    M[10, 12, 4] = 1.0
+    fl = fb.update_flow(M, win, gaussian=True)[..., 0]
+    k = np.exp(-np.arange(-3, 4) ** 2 / (2 * 0.9 ** 2))
+    k /= k.sum()
+    assert np.allclose(fl[7:14, 9:16] * (1 + 1e-3), np.outer(k, k), atol=1e-6)
+
+
+def test_oracle_recovers_a_translation_with_either_window():
+    a, b = _wave(120, 160), _wave(120, 160, 1.5, -0.75)
+    f = fb.calc_gray(a, b, fb.FarnebackParams(flags=256))[20:-20, 20:-20]
+    assert abs(f[..., 0].mean() - 1.5) < 0.05 and abs(f[..., 1].mean() + 0.75) < 0.05
+
+
 def test_oracle_recovers_a_translation():
     a, b = _wave(120, 160), _wave(120, 160, 1.5, -0.75)
     f = fb.calc_gray(a, b)[20:-20, 20:-20]
@@ -105,7 +132,7 @@ def test_oracle_identical_frames_give_no_interior_flow():
 
 def test_bad_parameters_are_rejected():
     a = _wave(40, 40)
-    for kw in (dict(pyrScale=1.0), dict(winSize=0), dict(polyN=0), dict(polyN=17), dict(flags=256)):
+    for kw in (dict(pyrScale=1.0), dict(winSize=0), dict(polyN=0), dict(polyN=17), dict(flags=4)):
         with pytest.raises(ValueError):
             fb.calc_gray(a, a, fb.FarnebackParams(**kw))
 
@@ -122,7 +149,7 @@ def test_library_parameter_table_without_a_gpu():
     for name, want in (("pyrScale", 0.5), ("polySigma", 1.5)):
         api.L.check(sr._lib.srx_flow_get_double(sr._h, name.encode(), api.C.byref(dv)))
         assert dv.value == want
-    for name, bad in (("winSize", 0), ("polyN", 17), ("flags", 256)):
+    for name, bad in (("winSize", 0), ("polyN", 17), ("flags", 4)):
         with pytest.raises(Exception):
             sr.flowSet(name, bad)
     with pytest.raises(Exception):
@@ -142,6 +169,8 @@ def test_library_parameter_table_without_a_gpu():
     (70, 90, 4, np.uint8, dict(pyrScale=0.7, numLevels=3, winSize=4, numIters=2)),
     (66, 68, 1, np.uint16, dict(numLevels=0, numIters=1)),
     (20, 12, 1, np.uint8, dict(numIters=2)),                     # smaller than the window and the border bands
+    (80, 100, 3, np.uint8, dict(flags=256, numIters=4)),         # Gaussian window
+    (50, 40, 1, np.uint8, dict(flags=256, winSize=21, numIters=2)),
 ])
 def test_gpu_flow_matches_oracle_bit_exact(rows, cols, ch, dtype, kw):
     from superresolution_amd import api
