@@ -91,6 +91,10 @@ __device__ __forceinline__ void stream_store(uint32_t* p, uint32_t v)
 {
     __builtin_nontemporal_store(v, p);
 }
+__device__ __forceinline__ void stream_store(uint2* p, uint32_t lo, uint32_t hi)
+{
+    __builtin_nontemporal_store(v2u{lo, hi}, (v2u*)p);
+}
 
 // volatile LDS vector access keeps 16-byte ds_read_b128 from being split into narrower reads
 typedef __attribute__((address_space(3))) const volatile v4i lds_cv4i;
@@ -1103,6 +1107,7 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
     int s = 0; // ring slot of the first row of the current LR row's window
     packed_floats<CH> yv = *(const packed_floats<CH>*)(yk + (size_t)y0 * w * CH);
     uint8_t place = flags[(size_t)y0 * strips_x];
+    uint32_t sg_above = 0; // sign word of the LR row before the current one
     for (int y = y0; y < y1; ++y)
     {
         const bool more = y + 1 < y1;
@@ -1154,12 +1159,19 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
             sum += (rr[0][c] + rr[4][c]) * k2;
             sg |= (uint32_t)((int)dsign(yv.v[c], sum) + 1) << (10 * c);
         }
+        // Cell (y-1) = {S(y-1), S(y)} leaves as one 8-byte store once both rows are known (whole cache
+        // lines per wave); only the cells at the tile's first and last row are written in halves, the other
+        // half coming from the tile above / below.
         if (owner)
         {
-            stream_store(sp + 2 * (size_t)y * w, sg);
-            if (y > 0)
+            if (y > y0)
+                stream_store((uint2*)(sp + 2 * (size_t)(y - 1) * w), sg_above, sg);
+            else if (y > 0)
                 stream_store(sp + 2 * (size_t)(y - 1) * w + 1, sg);
+            if (!more)
+                stream_store(sp + 2 * (size_t)y * w, sg);
         }
+        sg_above = sg;
 #pragma unroll
         for (int c = 0; c < CH; ++c)
             rr[0][c] = rr[4][c];
