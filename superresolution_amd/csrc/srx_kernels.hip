@@ -1379,14 +1379,18 @@ __device__ __forceinline__ int sign_of_difference(float t)
 #ifndef SRX_B_PARK
 #define SRX_B_PARK 2
 #endif
+// threads per block; a block covers 64 x (threads / 16) pixels
+#ifndef SRX_B_THREADS
+#define SRX_B_THREADS 256
+#endif
 
 // FOOT = cells per axis a target can touch: 2 (scale 4, pair plane) or 3 (scale 2, plain plane)
 template <int CH, int FOOT>
-__global__ __launch_bounds__(256, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVES - 1) void k_backproject_update_s4(
+__global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVES - 1) void k_backproject_update_s4(
     const float* __restrict__ X, float* __restrict__ X_out, int H, int W, size_t ps, PtrList dec_fwd,
     PtrList signs, int K, FastW fw, BtvW bw, double tau, double lambda, int tiles_x, unsigned n_tiles)
 {
-    constexpr int TYN = 16, PXT = 4;
+    constexpr int kThreads = SRX_B_THREADS, TYN = kThreads / 16, PXT = 4;
     constexpr int TW = 16 * PXT;        // 64 px
     constexpr int HALO = 3, HL = 4;     // halo; left halo padded to 4 px so that row loads are 16-byte aligned
     constexpr int PITCH = TW + HL + 4;  // 72 floats per LDS row: columns [j0-4, j0+68)
@@ -1398,7 +1402,7 @@ __global__ __launch_bounds__(256, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVES - 1) voi
     __shared__ uint4 lut[(FOOT == 2 ? 2 : 3) * kFwdLutSize];
     // regulariser values rest while the frame loop runs: the first kPark channels in LDS, the others in registers
     constexpr int kPark = SRX_B_PARK < CH ? SRX_B_PARK : CH;
-    __shared__ float park[(kPark > 0 ? kPark : 1) * PXT * 256];
+    __shared__ float park[(kPark > 0 ? kPark : 1) * PXT * kThreads];
     float keep[CH][PXT];
 
     const unsigned t = xcd_contiguous(blockIdx.x, n_tiles);
@@ -1441,13 +1445,13 @@ __global__ __launch_bounds__(256, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVES - 1) voi
     // ---- BTV regulariser, one channel at a time: the channel's tile of X (+3 px halo) is staged in LDS
     // (branch-free clamped loads, the next channel's issued before this channel's arithmetic starts)
     constexpr int NCH1 = LROWS * RV; // 16-byte chunks of one channel's tile
-    constexpr int NIT1 = (NCH1 + 255) / 256;
+    constexpr int NIT1 = (NCH1 + kThreads - 1) / kThreads;
     float4 stage[NIT1];
     auto load_stage = [&](int c) {
 #pragma unroll
         for (int it = 0; it < NIT1; ++it)
         {
-            const int idx = min(tid + it * 256, NCH1 - 1);
+            const int idx = min(tid + it * kThreads, NCH1 - 1);
             const int r = idx / RV, c4 = idx - r * RV;
             const int gi = min(max(i0 - HALO + r, 0), H - 1), gj = min(max(j0 - HL + 4 * c4, 0), W - 4);
             stage[it] = *(const float4*)(X + c * ps + (size_t)gi * W + gj);
@@ -1463,7 +1467,7 @@ __global__ __launch_bounds__(256, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVES - 1) voi
 #pragma unroll
             for (int it = 0; it < NIT1; ++it)
             {
-                const int idx = tid + it * 256;
+                const int idx = tid + it * kThreads;
                 const int r = idx / RV, c4 = idx - r * RV;
                 const int gi = i0 - HALO + r, gj = j0 - HL + 4 * c4;
                 // W and gj are multiples of 4: a chunk is entirely inside or outside the row
@@ -1550,7 +1554,7 @@ __global__ __launch_bounds__(256, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVES - 1) voi
             for (int e = 0; e < PXT; ++e)
             {
                 if (c < kPark)
-                    park[(c * PXT + e) * 256 + tid] = reg[e];
+                    park[(c * PXT + e) * kThreads + tid] = reg[e];
                 else
                     keep[c][e] = reg[e];
             }
@@ -1682,7 +1686,7 @@ __global__ __launch_bounds__(256, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVES - 1) voi
             float d = (float)(acc[p][c] - bias[p]) * 0.00390625f;
             if (lambda > 0)
             {
-                const float rv = c < kPark ? park[(c * PXT + p) * 256 + tid] : keep[c][p];
+                const float rv = c < kPark ? park[(c * PXT + p) * kThreads + tid] : keep[c][p];
                 const float rg = interior ? rv : 0.0f;
                 d = (float)((double)d + (double)rg * (-lambda));
             }
@@ -2078,10 +2082,11 @@ int launch_backproject_update(const float* X, float* X_out, int hr_rows, int hr_
     FastW fw;
     if (dec_fwd && backproject_fast_eligible(hr_rows, hr_cols, ch, scale, g, w) && make_fast_weights(g, scale, fw))
     {
-        const int tiles_x = (hr_cols + 63) / 64, tiles_y = (hr_rows + 15) / 16;
+        constexpr int tile_rows = SRX_B_THREADS / 16;
+        const int tiles_x = (hr_cols + 63) / 64, tiles_y = (hr_rows + tile_rows - 1) / tile_rows;
         const size_t ps = plane_stride_for((size_t)hr_rows * hr_cols);
         const unsigned n_tiles = (unsigned)tiles_x * tiles_y;
-        const dim3 gr(xcd_grid(n_tiles)), b(256);
+        const dim3 gr(xcd_grid(n_tiles)), b(SRX_B_THREADS);
 #define SRX_UPD(CHN, FT) hipLaunchKernelGGL((k_backproject_update_s4<CHN, FT>), gr, b, 0, st, X, X_out, hr_rows, hr_cols, ps, *dec_fwd, signs, K, fw, w, tau, lambda, tiles_x, n_tiles)
         if (ch == 1 && scale == 4)
             SRX_UPD(1, 2);
