@@ -585,7 +585,8 @@ inline dim3 grid2(int cols, int rows, dim3 b)
     } while (0)
 
 constexpr int kMaxScales = 16;
-constexpr int kPollStride = 32; // inner iterations enqueued between two looks at the error
+constexpr int kPollStride = 32; // most inner iterations enqueued before the first look at the error
+constexpr int kPollRest = 12;   // inner iterations enqueued between two later looks
 
 } // namespace
 
@@ -609,6 +610,10 @@ struct Tvl1::Impl
     DeviceBuffer I1x, I1y, I1wx, I1wy, grad, rho_c, p, err, raw0, raw1;
     DeviceBuffer u_alt, p_alt; // second set of u (2 planes) and p (4 planes) for the ping-pong of k_tvl1_iter
     PinnedBuffer host_err;
+    // inner iterations each (level, warp) ran in the previous call: consecutive frame pairs of a stream converge
+    // alike, so this sizes the first batch of launches (results do not depend on it, only the number of
+    // launches that find the iteration already converged)
+    std::vector<int> last_done;
 };
 
 int Tvl1::calc_images(const srx_image& f0, const srx_image& f1, const Tvl1Params& p, float* flow_uv,
@@ -716,6 +721,8 @@ int Tvl1::calc_gray(const float* I0, const float* I1, int rows, int cols, const 
         return rc;
     unsigned long long* herr = (unsigned long long*)m.host_err.get();
 
+    if (m.last_done.size() != (size_t)nscales * p.warps)
+        m.last_done.assign((size_t)nscales * p.warps, kPollStride - 1);
     const float l_t = (float)(p.lambda * p.theta), taut = (float)(p.tau / p.theta), theta = (float)p.theta;
     long long executed = 0;
     {
@@ -748,9 +755,11 @@ int Tvl1::calc_gray(const float* I0, const float* I1, int rows, int cols, const 
             float* pa[2] = {p11, m.p_alt.as<float>()};
             const dim3 bi(kItX, kItY);
             const dim3 gi = grid2(C, R, bi);
-            for (int it0 = 0; it0 < iters; it0 += kPollStride)
+            int& predicted = m.last_done[(size_t)s * p.warps + w];
+            for (int it0 = 0, it1 = 0; it0 < iters; it0 = it1)
             {
-                const int it1 = std::min(it0 + kPollStride, iters);
+                const int batch = it0 == 0 && predicted > 0 ? std::min(predicted + 1, kPollStride) : kPollRest;
+                it1 = std::min(it0 + batch, iters);
                 for (int it = it0; it < it1; ++it)
                 {
                     const int src = it & 1, dst = src ^ 1;
@@ -792,6 +801,7 @@ int Tvl1::calc_gray(const float* I0, const float* I1, int rows, int cols, const 
                 SRX_HIP(hipMemcpyAsync(pa[0], pa[1], 4 * n * sizeof(float), hipMemcpyDeviceToDevice, st));
             }
             executed += done;
+            predicted = done;
         }
         if (s > 0)
         {
