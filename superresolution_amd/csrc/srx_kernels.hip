@@ -1328,13 +1328,20 @@ struct __attribute__((packed, aligned(8))) uint4_a8
     uint32_t x, y, z, w;
 };
 
-// The BTV tile holds the pixels as floats with -0 folded into +0.  Then a - b is +0 exactly when
-// a == b and has the sign of the comparison otherwise (subnormal differences are kept: the kernels
-// run with fp32 denormals on), so the bit pattern of the difference, read as an integer and clamped
-// to [-1, 1], is sign(a - b).
-__device__ __forceinline__ float fold_zero(float x)
+// The BTV tile holds the pixels times 2^64, with -0 folded into +0.  A difference a - b of two such values is
+// +0 exactly when a == b, has the sign of the comparison otherwise, and is never smaller in magnitude than
+// 2^-85 (the smallest gap between two floats, 2^-149, times 2^64; scaling by a power of two is exact for
+// |pixel| < 2^63).  Clamping it to [-2^-85, 2^-85] therefore leaves sign(a - b) * 2^-85 - one float
+// instruction, and the sum of two such signs is exact.  The BTV weights are passed times 2^85, so that
+// weight * (sign + sign) is the reference's product, still exact, and the accumulation rounds as before.
+constexpr float kBtvTileScale = 0x1p64f, kBtvSignUnit = 0x1p-85f, kBtvWeightScale = 0x1p85f;
+__device__ __forceinline__ float btv_tile_value(float x)
 {
-    return x + 0.0f;
+    return __builtin_fmaf(x, kBtvTileScale, 0.0f);
+}
+__device__ __forceinline__ float scaled_sign(float d)
+{
+    return __builtin_amdgcn_fmed3f(d, -kBtvSignUnit, kBtvSignUnit);
 }
 // a * b + c on the low 24 bits of a and b: one v_mad_u32_u24 (the compiler prefers two multiplies and a
 // three-way add for a pair of these)
@@ -1344,12 +1351,6 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-__device__ __forceinline__ int sign_of_difference(float t)
-{
-    int s;
-    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(s) : "v"(__float_as_int(t)));
-    return s;
-}
 
 // Back-projection of all K frames + BTV regulariser + update for one 64x16 tile
 // of HR pixels per block; each thread owns 4 consecutive pixels of one row.
@@ -1357,11 +1358,12 @@ __device__ __forceinline__ int sign_of_difference(float t)
 //  * BTV, one channel after the other: the channel's tile of X (+3 px halo) is
 //    staged in LDS (the next channel's loads are in flight meanwhile);
 //    sign(a-b) is a float subtract (two at a time where the window registers
-//    pair up) and an integer clamp; accumulation order is the reference's
-//    (lib/src/btv_l1.cpp:221-233).  A small tile and few live registers keep 7
-//    waves per SIMD resident, which is what hides the gather latency of the
-//    frame loop.  The results rest in LDS / registers while that loop runs.
-//    NaN - x counts as +1 instead of comparing unordered.
+//    pair up) and a float clamp (scaled_sign above); accumulation order is the
+//    reference's (lib/src/btv_l1.cpp:221-233).  A small tile and few live
+//    registers keep 6-7 waves per SIMD resident, which is what hides the gather
+//    latency of the frame loop.  The results rest in LDS / registers while that
+//    loop runs.  Pixels are taken to be finite and smaller than 2^63 in
+//    magnitude; a NaN pixel does not compare unordered as in the reference.
 //  * per frame: one 16-byte load of 4 decoded forward-map entries (fetched one
 //    frame ahead), then per pixel one 16-byte read of the 2x2 block of sign
 //    cells from the pair plane, times the entry's integer weights.  A sign word
@@ -1476,7 +1478,7 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVE
                 {
                     const float4 v = stage[it];
                     // outside the image the tile holds 0; those cells are never read by an interior pixel
-                    *(float4*)&tile[4 * idx] = in ? make_float4(fold_zero(v.x), fold_zero(v.y), fold_zero(v.z), fold_zero(v.w))
+                    *(float4*)&tile[4 * idx] = in ? make_float4(btv_tile_value(v.x), btv_tile_value(v.y), btv_tile_value(v.z), btv_tile_value(v.w))
                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
@@ -1536,16 +1538,17 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVE
                         dp[0] = cf[HL] - pf[HL + l], dm[0] = cf[HL] - mf[HL - l];
                         dp[3] = cf[HL + 3] - pf[HL + 3 + l], dm[3] = cf[HL + 3] - mf[HL + 3 - l];
                     }
-                    float df[PXT];
+                    float sp[PXT], sm[PXT];
 #pragma unroll
                     for (int e = 0; e < PXT; ++e)
-                        df[e] = (float)(sign_of_difference(dp[e]) + sign_of_difference(dm[e]));
-                    // w * d is exact (d in -2..2), so the fused form rounds once, like acc += w * d
+                        sp[e] = scaled_sign(dp[e]), sm[e] = scaled_sign(dm[e]);
+                    // (w 2^85) * ((s + s') 2^-85) = w * d exactly (d in -2..2), so the fused form rounds once,
+                    // like acc += w * d
 #pragma unroll
                     for (int e = 0; e < PXT; e += 2)
                     {
-                        const v2f r = __builtin_elementwise_fma(v2f{wt, wt}, v2f{df[e], df[e + 1]},
-                                                                v2f{reg[e], reg[e + 1]});
+                        const v2f d2 = v2f{sp[e], sp[e + 1]} + v2f{sm[e], sm[e + 1]};
+                        const v2f r = __builtin_elementwise_fma(v2f{wt, wt}, d2, v2f{reg[e], reg[e + 1]});
                         reg[e] = r.x, reg[e + 1] = r.y;
                     }
                 }
@@ -2087,7 +2090,10 @@ int launch_backproject_update(const float* X, float* X_out, int hr_rows, int hr_
         const size_t ps = plane_stride_for((size_t)hr_rows * hr_cols);
         const unsigned n_tiles = (unsigned)tiles_x * tiles_y;
         const dim3 gr(xcd_grid(n_tiles)), b(SRX_B_THREADS);
-#define SRX_UPD(CHN, FT) hipLaunchKernelGGL((k_backproject_update_s4<CHN, FT>), gr, b, 0, st, X, X_out, hr_rows, hr_cols, ps, *dec_fwd, signs, K, fw, w, tau, lambda, tiles_x, n_tiles)
+        BtvW ws = w; // weights times 2^85 (exact), see scaled_sign
+        for (int i = 0; i < kMaxBtvWeights; ++i)
+            ws.w[i] *= kBtvWeightScale;
+#define SRX_UPD(CHN, FT) hipLaunchKernelGGL((k_backproject_update_s4<CHN, FT>), gr, b, 0, st, X, X_out, hr_rows, hr_cols, ps, *dec_fwd, signs, K, fw, ws, tau, lambda, tiles_x, n_tiles)
         if (ch == 1 && scale == 4)
             SRX_UPD(1, 2);
         else if (ch == 1)
