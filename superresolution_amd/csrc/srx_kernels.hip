@@ -1406,6 +1406,7 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVE
     constexpr int kPark = SRX_B_PARK < CH ? SRX_B_PARK : CH;
     __shared__ float park[(kPark > 0 ? kPark : 1) * PXT * kThreads];
     float keep[CH][PXT];
+    float centre[CH][PXT];
 
     const unsigned t = xcd_contiguous(blockIdx.x, n_tiles);
     if (t >= n_tiles)
@@ -1491,6 +1492,10 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVE
             for (int v = 0; v < NV; ++v)
                 cv[v] = tp[v];
             const float* cf = (const float*)cv;
+            // the thread's own pixels, unscaled again (exact), for the update at the end
+#pragma unroll
+            for (int e = 0; e < PXT; ++e)
+                centre[c][e] = cf[HL + e] * (1.0f / kBtvTileScale);
             float reg[PXT];
 #pragma unroll
             for (int e = 0; e < PXT; ++e)
@@ -1678,9 +1683,21 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVE
 #pragma unroll
     for (int c = 0; c < CH; ++c)
     {
-        // the centre pixels are read again (they are in L2), the regulariser comes from its parking slot
-        const float4 ctr = *(const float4*)(X + c * ps + pix);
-        const float cxv[PXT] = {ctr.x, ctr.y, ctr.z, ctr.w};
+        // the regulariser comes from its parking slot
+        // with the regulariser on, the centre pixels were kept from the tile (-0 arrives as +0, which the
+        // double sum below maps to the same result); otherwise they are read here
+        float cxv[PXT];
+        if (lambda > 0)
+        {
+#pragma unroll
+            for (int p = 0; p < PXT; ++p)
+                cxv[p] = centre[c][p];
+        }
+        else
+        {
+            const float4 ctr = *(const float4*)(X + c * ps + pix);
+            cxv[0] = ctr.x, cxv[1] = ctr.y, cxv[2] = ctr.z, cxv[3] = ctr.w;
+        }
         float outv[PXT];
 #pragma unroll
         for (int p = 0; p < PXT; ++p)
