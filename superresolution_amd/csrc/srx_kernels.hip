@@ -1546,7 +1546,12 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVE
                     float sp[PXT], sm[PXT];
 #pragma unroll
                     for (int e = 0; e < PXT; ++e)
-                        sp[e] = scaled_sign(dp[e]), sm[e] = scaled_sign(dm[e]);
+                        sp[e] = scaled_sign(dp[e]);
+                    // within the row (m = 0) the backward difference of pixel e is minus the forward difference
+                    // of pixel e - l (a - b == -(b - a) exactly), which this thread has when e >= l
+#pragma unroll
+                    for (int e = 0; e < PXT; ++e)
+                        sm[e] = (m == 0 && e >= l) ? -sp[e - l] : scaled_sign(dm[e]);
                     // (w 2^85) * ((s + s') 2^-85) = w * d exactly (d in -2..2), so the fused form rounds once,
                     // like acc += w * d
 #pragma unroll
