@@ -221,7 +221,11 @@ class BTV_L1 : public SuperResolution
 {
   public:
     // device: GPU ordinal; -1 creates a dry-run object (host bookkeeping only)
-    explicit BTV_L1(int device = 0) { check(srx_create_btvl1(device, &h_)); }
+    explicit BTV_L1(int device = 0)
+    {
+        check(srx_create_btvl1(device, &h_));
+        flow_ = std::make_shared<Farneback>(); // opticalFlow = new Farneback, lib/src/btv_l1.cpp:287 (the library's default)
+    }
     ~BTV_L1() override { srx_destroy(h_); }
     BTV_L1(const BTV_L1&) = delete;
     BTV_L1& operator=(const BTV_L1&) = delete;

@@ -154,7 +154,7 @@ class BTV_L1:
         self._h = h
         self._keep = []
         self._src = None
-        self._flow = None
+        self._flow = Farneback()  # opticalFlow = new Farneback, lib/src/btv_l1.cpp:287 (the library's default)
         self._cb = None
 
     def __del__(self):

@@ -149,6 +149,7 @@ int main()
     // the reference's default flow class as a built-in: members travel with setOpticalFlow, bad values throw
     {
         BTV_L1 fbsr(-1);
+        REQUIRE(dynamic_cast<Farneback*>(fbsr.getOpticalFlow().get()) != nullptr); // the default flow
         auto fb = std::make_shared<Farneback>();
         REQUIRE(fb->pyrScale == 0.5 && fb->numLevels == 5 && fb->winSize == 13 && fb->numIters == 10 &&
                 fb->polyN == 5 && fb->polySigma == 1.1 && fb->flags == 0); // lib/src/optical_flow.cpp:41-50
