@@ -38,6 +38,10 @@ def _describe(a, keep: list) -> L.SrxImage:
         keep.append(a)
         im.data = a.data_ptr()
         im.mem = L.SRX_MEM_DEVICE if a.is_cuda else L.SRX_MEM_HOST
+        if a.is_cuda:
+            # the library works on a stream of its own: whatever torch still has queued for this tensor must
+            # have run before the pointer crosses the C ABI (which takes finished buffers, like a cv::Mat)
+            torch.cuda.current_stream(a.device).synchronize()
         if a.dtype == torch.uint8:
             im.depth = L.SRX_8U
         elif a.dtype == torch.float32:

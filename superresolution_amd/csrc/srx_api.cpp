@@ -305,6 +305,8 @@ int srx_handle::read_ahead()
     {
         if (int rc = look_dev.reserve(rowbytes * rows))
             return rc;
+        // the main stream may still be reading look_dev (the frame of this call) and writing prevFrame
+        SRX_HIP(hipStreamWaitEvent(stream2, prev_ready, 0));
         if (int rc = copy_to_device(f, look_dev.get(), stream2))
             return rc;
         look_hdr.data = look_dev.get();
