@@ -133,7 +133,7 @@ class Solver
     // Optional per-kernel timing with HIP events on the solver's stream: the forward
     // and back-projection launches of every kTimingStride-th iteration are bracketed
     // by events that are read back (after a stream synchronise) by collect_timing().
-    static constexpr int kTimingStride = 4;
+    static constexpr int kTimingStride = 8;
     void enable_timing(bool on) { timing_ = on; }
     bool timing() const { return timing_; }
     int collect_timing(hipStream_t st);
