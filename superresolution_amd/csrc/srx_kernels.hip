@@ -42,7 +42,45 @@
 
 
 #include <atomic>
+#include <cmath>
 #include <cstring>
+
+// Diagnostic builds only (-DSRX_STAMPS): every wave of the update kernel records s_memtime at its phase
+// boundaries into a device array that srx_debug_stamps copies out.  No stamp exists in the product build.
+#ifdef SRX_STAMPS
+constexpr int kStampSlots = 8;
+__device__ unsigned long long g_stamps[kStampSlots << 16];
+#define SRX_STAMP(slot)                                                                                       \
+    do                                                                                                        \
+    {                                                                                                         \
+        if ((threadIdx.x & 63) == 0)                                                                          \
+        {                                                                                                     \
+            const unsigned wave_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                       \
+            if (wave_ < (1u << 16))                                                                           \
+                g_stamps[wave_ * kStampSlots + (slot)] = __builtin_amdgcn_s_memtime();                        \
+        }                                                                                                     \
+    } while (0)
+extern "C" __attribute__((visibility("default"))) int srx_debug_stamps(unsigned long long* dst, size_t count)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), count * sizeof(unsigned long long));
+}
+#define SRX_TICK() __builtin_amdgcn_s_memtime()
+#define SRX_FWD_STAMPS(v0, v1, v2, v3, v4)                                                                   \
+    do                                                                                                        \
+    {                                                                                                         \
+        if ((threadIdx.x & 63) == 0)                                                                          \
+        {                                                                                                     \
+            const unsigned wave_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                       \
+            if (wave_ < (1u << 16))                                                                           \
+            {                                                                                                 \
+                unsigned long long* o_ = g_stamps + wave_ * kStampSlots;                                      \
+                o_[0] = (v0), o_[1] = (v1), o_[2] = (v2), o_[3] = (v3), o_[4] = (v4);                         \
+            }                                                                                                 \
+        }                                                                                                     \
+    } while (0)
+#else
+#define SRX_STAMP(slot) do { } while (0)
+#endif
 
 namespace srx
 {
@@ -841,6 +879,9 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
     constexpr int kItemsPerRow = CH * kFwdQuads;
     constexpr int kRingBytes = kFwdRing * kSlotBytes;
 
+#ifdef SRX_STAMPS
+    const unsigned long long t_begin = SRX_TICK();
+#endif
     const unsigned tile = xcd_contiguous(blockIdx.x, n_tiles);
     if (tile >= n_tiles)
         return;
@@ -891,8 +932,32 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
         float* d = (float*)(ring + slot * kSlotBytes + c * kFwdRowBytes) + q;
         d[0] = v.x, d[kFwdQuads] = v.y, d[2 * kFwdQuads] = v.z, d[3 * kFwdQuads] = v.w;
     };
-    for (int item = tid; item < kFwdSpan * kItemsPerRow; item += nthreads)
-        stage_piece(item, rbase, 0);
+    // the tile's first window: several loads in flight per thread (one at a time, the start-up of a tile
+    // is a chain of memory latencies, a sixth of the kernel's time)
+    {
+        constexpr int kTotal = kFwdSpan * kItemsPerRow, kBatch = 8;
+        for (int first = tid; first < kTotal; first += kBatch * nthreads)
+        {
+            float4 v[kBatch];
+            float* d[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u)
+            {
+                const int item = min(first + u * nthreads, kTotal - 1);
+                const int rr_ = item / kItemsPerRow, rem = item - rr_ * kItemsPerRow;
+                const int c = rem / kFwdQuads, q = rem - c * kFwdQuads;
+                const int row = rbase + rr_, col = c0 + 4 * q;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((unsigned)row < (unsigned)H && (unsigned)col < (unsigned)W)
+                    v[u] = *(const float4*)(X + c * ps + (size_t)row * W + col);
+                d[u] = (float*)(ring + rr_ * kSlotBytes + c * kFwdRowBytes) + q;
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u)
+                if (first + u * nthreads < kTotal)
+                    d[u][0] = v[u].x, d[u][kFwdQuads] = v[u].y, d[u][2 * kFwdQuads] = v[u].z, d[u][3 * kFwdQuads] = v[u].w;
+        }
+    }
 
     // Pieces of this thread within a batch of four HR rows (fixed for the whole tile).  Blocks of
     // many waves (the common case) own at most two pieces per batch and load them a whole LR row
@@ -1108,8 +1173,14 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
     packed_floats<CH> yv = *(const packed_floats<CH>*)(yk + (size_t)y0 * w * CH);
     uint8_t place = flags[(size_t)y0 * strips_x];
     uint32_t sg_above = 0; // sign word of the LR row before the current one
+#ifdef SRX_STAMPS
+    unsigned long long t_compute = 0, t_put = 0, t_barrier = 0, t_prologue = SRX_TICK() - t_begin;
+#endif
     for (int y = y0; y < y1; ++y)
     {
+#ifdef SRX_STAMPS
+        const unsigned long long t_a = SRX_TICK();
+#endif
         const bool more = y + 1 < y1;
         const uint8_t place_next = flags[(size_t)min(y + 1, h - 1) * strips_x];
         float4 sv[2];
@@ -1179,6 +1250,9 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
         for (int r = 0; r < 4; ++r)
             mc[r] = mn[r];
         yv = yn;
+#ifdef SRX_STAMPS
+        const unsigned long long t_b = SRX_TICK();
+#endif
         if (more)
         {
             // rows 4y+3+My .. 4y+6+My join the window; they start kFwdSpan rows below its first row
@@ -1190,8 +1264,17 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
                     stage_piece(item, 4 * y + 3 + kFwdMy, slot_first);
         }
         s = s + 4 >= kFwdRing ? s + 4 - kFwdRing : s + 4;
+#ifdef SRX_STAMPS
+        const unsigned long long t_c = SRX_TICK();
+#endif
         __syncthreads();
+#ifdef SRX_STAMPS
+        t_compute += t_b - t_a, t_put += t_c - t_b, t_barrier += SRX_TICK() - t_c;
+#endif
     }
+#ifdef SRX_STAMPS
+    SRX_FWD_STAMPS(t_prologue, t_compute, t_put, t_barrier, SRX_TICK() - t_begin);
+#endif
 }
 
 // value held by lane+1 of the wave (0 in lane 63)
@@ -1328,20 +1411,34 @@ struct __attribute__((packed, aligned(8))) uint4_a8
     uint32_t x, y, z, w;
 };
 
-// The BTV tile holds the pixels times 2^64, with -0 folded into +0.  A difference a - b of two such values is
-// +0 exactly when a == b, has the sign of the comparison otherwise, and is never smaller in magnitude than
-// 2^-85 (the smallest gap between two floats, 2^-149, times 2^64; scaling by a power of two is exact for
-// |pixel| < 2^63).  Clamping it to [-2^-85, 2^-85] therefore leaves sign(a - b) * 2^-85 - one float
-// instruction, and the sum of two such signs is exact.  The BTV weights are passed times 2^85, so that
-// weight * (sign + sign) is the reference's product, still exact, and the accumulation rounds as before.
-constexpr float kBtvTileScale = 0x1p64f, kBtvSignUnit = 0x1p-85f, kBtvWeightScale = 0x1p85f;
+// Comparisons of pixel pairs for the BTV term, two pixels per instruction.  The BTV tile holds the pixels
+// times 2^64 (exact for |pixel| < 2^63).  A difference d = a - b of two such values is +-0 exactly when
+// a == b, has the sign of the comparison otherwise, and is never smaller in magnitude than 2^-85 (the
+// smallest gap between two floats, 2^-149, times 2^64).  d * 2^86 + 0.5, clamped to [0, 1] by the
+// instruction's output modifier, is therefore 1, 0.5 or 0 for a > b, a == b, a < b: (sign(a - b) + 1) / 2
+// from one packed multiply-add.  The reference's sign(a - b) - sign(c - a) (lib/src/btv_l1.cpp:221-233) is
+// then 2 * (half_step(a - b) - half_step(c - a)); the BTV weights are passed times 2 (exact), so that the
+// multiply-add of the accumulation forms the reference's product, still exact, and rounds as before.
+// A tile whose scaled values are not all finite (NaN or infinite pixels, magnitudes of 2^63 and more)
+// takes the comparison path on the unscaled values instead, which is the reference's diffSign
+// (lib/src/btv_l1.cpp:138-141) literally.
+constexpr float kBtvTileScale = 0x1p64f, kBtvStepScale = 0x1p86f;
 __device__ __forceinline__ float btv_tile_value(float x)
 {
-    return __builtin_fmaf(x, kBtvTileScale, 0.0f);
+    return x * kBtvTileScale;
 }
-__device__ __forceinline__ float scaled_sign(float d)
+// (sign(d) + 1) / 2 for both halves of d; `scale2` holds kBtvStepScale twice
+__device__ __forceinline__ v2f half_step2(v2f d, v2f scale2)
 {
-    return __builtin_amdgcn_fmed3f(d, -kBtvSignUnit, kBtvSignUnit);
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, 0.5 op_sel_hi:[1,1,0] clamp" : "=v"(r) : "v"(d), "v"(scale2));
+    return r;
+}
+__device__ __forceinline__ float half_step(float d, float scale)
+{
+    float r;
+    asm("v_fma_f32 %0, %1, %2, 0.5 clamp" : "=v"(r) : "v"(d), "v"(scale));
+    return r;
 }
 // a * b + c on the low 24 bits of a and b: one v_mad_u32_u24 (the compiler prefers two multiplies and a
 // three-way add for a pair of these)
@@ -1356,14 +1453,13 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
 // of HR pixels per block; each thread owns 4 consecutive pixels of one row.
 // X and X_out are planar.
 //  * BTV, one channel after the other: the channel's tile of X (+3 px halo) is
-//    staged in LDS (the next channel's loads are in flight meanwhile);
-//    sign(a-b) is a float subtract (two at a time where the window registers
-//    pair up) and a float clamp (scaled_sign above); accumulation order is the
-//    reference's (lib/src/btv_l1.cpp:221-233).  A small tile and few live
-//    registers keep 6-7 waves per SIMD resident, which is what hides the gather
-//    latency of the frame loop.  The results rest in LDS / registers while that
-//    loop runs.  Pixels are taken to be finite and smaller than 2^63 in
-//    magnitude; a NaN pixel does not compare unordered as in the reference.
+//    staged in LDS (the next channel's loads are in flight meanwhile); the
+//    comparisons come from half_step2 above, two pixels per instruction, or
+//    from plain compares for a tile whose scaled values are not all finite;
+//    accumulation order is the reference's (lib/src/btv_l1.cpp:221-233).  The
+//    kernel is bound by the issue of vector instructions (one per SIMD every
+//    four cycles, whatever the instruction), so what counts is their number.
+//    The results rest in LDS / registers while the frame loop runs.
 //  * per frame: one 16-byte load of 4 decoded forward-map entries (fetched one
 //    frame ahead), then per pixel one 16-byte read of the 2x2 block of sign
 //    cells from the pair plane, times the entry's integer weights.  A sign word
@@ -1426,6 +1522,7 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVE
     const bool live = (i0 + ty) < H && (j0 + tx * PXT) < W; // W is a multiple of 4: a thread's pixels are all in or all out
     const size_t pix = (size_t)i * W + j;
 
+    SRX_STAMP(0);
     // first frame's map entries: issued before the tile is staged
     uint4 cur = make_uint4(0, 0, 0, 0);
     if (K > 0)
@@ -1461,12 +1558,21 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVE
         }
     };
     const int lrow = ty + HALO;
+    // one verdict per wave and channel: is every scaled value of the wave's share of the tile finite
+    __shared__ uint32_t odd_values[CH][kThreads / 64];
+    __shared__ float whole_weights[22]; // for the tiles that take the comparison path
+    typedef const float __attribute__((address_space(3))) lds_cfloat;
+    if (tid >= 64 && tid < 64 + 22)
+        whole_weights[tid - 64] = bw.w[tid - 64] * 0.5f;
     if (lambda > 0)
     {
         load_stage(0);
+        const v2f step2 = v2f{kBtvStepScale, kBtvStepScale};
 #pragma unroll
         for (int c = 0; c < CH; ++c)
         {
+            // 0 * value summed over the thread's share: 0 while every scaled value is finite, NaN otherwise
+            v2f weird = v2f{0.0f, 0.0f};
 #pragma unroll
             for (int it = 0; it < NIT1; ++it)
             {
@@ -1478,100 +1584,156 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVE
                 if (idx < NCH1)
                 {
                     const float4 v = stage[it];
+                    const v2f lo = v2f{btv_tile_value(v.x), btv_tile_value(v.y)}, hi = v2f{btv_tile_value(v.z), btv_tile_value(v.w)};
+                    weird = __builtin_elementwise_fma(lo, v2f{0.0f, 0.0f}, weird);
+                    weird = __builtin_elementwise_fma(hi, v2f{0.0f, 0.0f}, weird);
                     // outside the image the tile holds 0; those cells are never read by an interior pixel
-                    *(float4*)&tile[4 * idx] = in ? make_float4(btv_tile_value(v.x), btv_tile_value(v.y), btv_tile_value(v.z), btv_tile_value(v.w))
-                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+                    *(float4*)&tile[4 * idx] = in ? make_float4(lo.x, lo.y, hi.x, hi.y) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
+            }
+            {
+                const bool odd = !(weird.x == 0.0f) || !(weird.y == 0.0f);
+                const bool any = __builtin_amdgcn_ballot_w64(odd) != 0;
+                if ((tid & 63) == 0)
+                    odd_values[c][tid >> 6] = any ? 1u : 0u;
             }
             __syncthreads();
-            if (c + 1 < CH)
-                load_stage(c + 1);
-            lds_cv4i* tp = (lds_cv4i*)tile + lrow * RV + tx; // window start of the centre row
-            v4i cv[NV];
+            if (c == 0)
+                SRX_STAMP(1);
+            bool plain = true;
 #pragma unroll
-            for (int v = 0; v < NV; ++v)
-                cv[v] = tp[v];
-            const float* cf = (const float*)cv;
-            // the thread's own pixels, unscaled again (exact), for the update at the end
-#pragma unroll
-            for (int e = 0; e < PXT; ++e)
-                centre[c][e] = cf[HL + e] * (1.0f / kBtvTileScale);
-            float reg[PXT];
-#pragma unroll
-            for (int e = 0; e < PXT; ++e)
-                reg[e] = 0.0f;
-
-            int ind = 0;
-#pragma unroll
-            for (int m = 0; m <= 3; ++m)
+            for (int wv = 0; wv < kThreads / 64; ++wv)
+                plain = plain && odd_values[c][wv] == 0u;
+            v2f reg01 = v2f{0.0f, 0.0f}, reg23 = v2f{0.0f, 0.0f};
+            if (__builtin_expect(plain, 1))
             {
-                v4i pv[NV], mv[NV];
+                if (c + 1 < CH)
+                    load_stage(c + 1);
+                lds_cv4i* tp = (lds_cv4i*)tile + lrow * RV + tx; // window start of the centre row
+                v4i cv[NV];
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
-                {
-                    pv[v] = m == 0 ? cv[v] : tp[m * RV + v];
-                    mv[v] = m == 0 ? cv[v] : tp[-m * RV + v];
-                }
-                const float* pf = (const float*)pv;
-                const float* mf = (const float*)mv;
+                    cv[v] = tp[v];
+                const float* cf = (const float*)cv;
+                // the thread's own pixels, unscaled again (exact), for the update at the end
 #pragma unroll
-                for (int l = 3; l + m >= 0; --l, ++ind)
+                for (int e = 0; e < PXT; ++e)
+                    centre[c][e] = cf[HL + e] * (1.0f / kBtvTileScale);
+                const v2f c01 = *(const v2f*)&cf[HL], c23 = *(const v2f*)&cf[HL + 2], c12 = v2f{cf[HL + 1], cf[HL + 2]};
+                int ind = 0;
+#pragma unroll
+                for (int m = 0; m <= 3; ++m)
                 {
-                    if (m == 0 && l == 0)
-                        continue; // both signs compare the pixel with itself: adds w * 0
-                    const float wt = bw.w[ind];
-                    // differences two at a time (v_pk_add_f32) where the window registers pair up:
-                    // pixels (0,1),(2,3) for even l, pixels (1,2) for odd l
-                    float dp[PXT], dm[PXT];
-                    if ((l & 1) == 0)
+                    v4i pv[NV], mv[NV];
+#pragma unroll
+                    for (int v = 0; v < NV; ++v)
                     {
+                        pv[v] = m == 0 ? cv[v] : tp[m * RV + v];
+                        mv[v] = m == 0 ? cv[v] : tp[-m * RV + v];
+                    }
+                    const float* pf = (const float*)pv;
+                    const float* mf = (const float*)mv;
 #pragma unroll
-                        for (int e = 0; e < PXT; e += 2)
+                    for (int l = 3; l + m >= 0; --l, ++ind)
+                    {
+                        if (m == 0 && l == 0)
+                            continue; // both signs compare the pixel with itself: adds w * 0
+                        const float wt = bw.w[ind]; // twice the weight
+                        // fp[e] = half_step(X(p) - X(p + d)), bp[e] = half_step(X(p - d) - X(p)) for the
+                        // thread's pixels e = 0..3.  The window registers pair up for pixels (0,1), (2,3) when
+                        // l is even - subtraction and step are then packed - and for pixels (1,2) when l is odd:
+                        // packed subtraction, and scalar steps that write into the pairs (0,1), (2,3).
+                        float fp[PXT], bp[PXT];
+                        if ((l & 1) == 0)
                         {
-                            const v2f c2 = *(const v2f*)&cf[HL + e];
-                            const v2f a = c2 - *(const v2f*)&pf[HL + e + l];
-                            const v2f b = c2 - *(const v2f*)&mf[HL + e - l];
-                            dp[e] = a.x, dp[e + 1] = a.y, dm[e] = b.x, dm[e + 1] = b.y;
+                            const v2f a = half_step2(c01 - *(const v2f*)&pf[HL + l], step2);
+                            const v2f b = half_step2(c23 - *(const v2f*)&pf[HL + 2 + l], step2);
+                            fp[0] = a.x, fp[1] = a.y, fp[2] = b.x, fp[3] = b.y;
                         }
-                    }
-                    else
-                    {
-                        const v2f c2 = v2f{cf[HL + 1], cf[HL + 2]};
-                        const v2f a = c2 - *(const v2f*)&pf[HL + 1 + l];
-                        const v2f b = c2 - *(const v2f*)&mf[HL + 1 - l];
-                        dp[1] = a.x, dp[2] = a.y, dm[1] = b.x, dm[2] = b.y;
-                        dp[0] = cf[HL] - pf[HL + l], dm[0] = cf[HL] - mf[HL - l];
-                        dp[3] = cf[HL + 3] - pf[HL + 3 + l], dm[3] = cf[HL + 3] - mf[HL + 3 - l];
-                    }
-                    float sp[PXT], sm[PXT];
+                        else
+                        {
+                            const v2f a = c12 - *(const v2f*)&pf[HL + 1 + l];
+                            fp[1] = half_step(a.x, kBtvStepScale), fp[2] = half_step(a.y, kBtvStepScale);
+                            fp[0] = half_step(cf[HL] - pf[HL + l], kBtvStepScale);
+                            fp[3] = half_step(cf[HL + 3] - pf[HL + 3 + l], kBtvStepScale);
+                        }
+                        if (m == 0)
+                        {
+                            // within the row X(p - d) - X(p) is the forward difference of pixel e - l, which
+                            // this thread has when e >= l
 #pragma unroll
-                    for (int e = 0; e < PXT; ++e)
-                        sp[e] = scaled_sign(dp[e]);
-                    // within the row (m = 0) the backward difference of pixel e is minus the forward difference
-                    // of pixel e - l (a - b == -(b - a) exactly), which this thread has when e >= l
-#pragma unroll
-                    for (int e = 0; e < PXT; ++e)
-                        sm[e] = (m == 0 && e >= l) ? -sp[e - l] : scaled_sign(dm[e]);
-                    // (w 2^85) * ((s + s') 2^-85) = w * d exactly (d in -2..2), so the fused form rounds once,
-                    // like acc += w * d
-#pragma unroll
-                    for (int e = 0; e < PXT; e += 2)
-                    {
-                        const v2f d2 = v2f{sp[e], sp[e + 1]} + v2f{sm[e], sm[e + 1]};
-                        const v2f r = __builtin_elementwise_fma(v2f{wt, wt}, d2, v2f{reg[e], reg[e + 1]});
-                        reg[e] = r.x, reg[e + 1] = r.y;
+                            for (int e = 0; e < PXT; ++e)
+                                bp[e] = e >= l ? fp[e - l] : half_step(mf[HL + e - l] - cf[HL + e], kBtvStepScale);
+                        }
+                        else if ((l & 1) == 0)
+                        {
+                            const v2f a = half_step2(*(const v2f*)&mf[HL - l] - c01, step2);
+                            const v2f b = half_step2(*(const v2f*)&mf[HL + 2 - l] - c23, step2);
+                            bp[0] = a.x, bp[1] = a.y, bp[2] = b.x, bp[3] = b.y;
+                        }
+                        else
+                        {
+                            const v2f a = *(const v2f*)&mf[HL + 1 - l] - c12;
+                            bp[1] = half_step(a.x, kBtvStepScale), bp[2] = half_step(a.y, kBtvStepScale);
+                            bp[0] = half_step(mf[HL - l] - cf[HL], kBtvStepScale);
+                            bp[3] = half_step(mf[HL + 3 - l] - cf[HL + 3], kBtvStepScale);
+                        }
+                        // (2 w) * (fp - bp) = w * (sign - sign) exactly, so the fused form rounds once, like
+                        // the reference's acc += w * d
+                        reg01 = __builtin_elementwise_fma(v2f{wt, wt}, v2f{fp[0], fp[1]} - v2f{bp[0], bp[1]}, reg01);
+                        reg23 = __builtin_elementwise_fma(v2f{wt, wt}, v2f{fp[2], fp[3]} - v2f{bp[2], bp[3]}, reg23);
                     }
                 }
             }
-#pragma unroll
-            for (int e = 0; e < PXT; ++e)
+            else
             {
-                if (c < kPark)
-                    park[(c * PXT + e) * kThreads + tid] = reg[e];
-                else
-                    keep[c][e] = reg[e];
+                // the tile again, unscaled, and the regulariser by comparisons (rare)
+#pragma unroll
+                for (int it = 0; it < NIT1; ++it)
+                {
+                    const int idx = tid + it * kThreads;
+                    const int r = idx / RV, c4 = idx - r * RV;
+                    const int gi = i0 - HALO + r, gj = j0 - HL + 4 * c4;
+                    const bool in = gi >= 0 && gi < H && gj >= 0 && gj < W;
+                    if (idx < NCH1)
+                        *(float4*)&tile[4 * idx] = in ? stage[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                __syncthreads();
+                if (c + 1 < CH)
+                    load_stage(c + 1);
+                lds_cfloat* tc = (lds_cfloat*)tile + lrow * PITCH + 4 * tx + HL;
+#pragma unroll
+                for (int e = 0; e < PXT; ++e)
+                    centre[c][e] = tc[e];
+                lds_cfloat* wl = (lds_cfloat*)whole_weights;
+                float reg[PXT] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+                for (int m = 0; m <= 3; ++m)
+                {
+#pragma unroll 1
+                    for (int l = 3; l + m >= 0; --l)
+                    {
+                        const float wt = *wl++;
+#pragma unroll
+                        for (int e = 0; e < PXT; ++e)
+                            reg[e] += wt * (dsign(centre[c][e], tc[m * PITCH + e + l]) - dsign(tc[-m * PITCH + e - l], centre[c][e]));
+                    }
+                }
+                reg01 = v2f{reg[0], reg[1]}, reg23 = v2f{reg[2], reg[3]};
+            }
+            {
+                const float reg[PXT] = {reg01.x, reg01.y, reg23.x, reg23.y};
+#pragma unroll
+                for (int e = 0; e < PXT; ++e)
+                {
+                    if (c < kPark)
+                        park[(c * PXT + e) * kThreads + tid] = reg[e];
+                    else
+                        keep[c][e] = reg[e];
+                }
             }
             __syncthreads(); // the tile is rewritten for the next channel
+            SRX_STAMP(2 + c);
         }
     }
     else
@@ -1682,6 +1844,7 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVE
         if (k < K)
             frame(k, cur, alt);
     }
+    SRX_STAMP(5);
     // ---- update
     if (!live)
         return;
@@ -1719,6 +1882,7 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVE
         }
         *(float4*)(X_out + c * ps + pix) = make_float4(outv[0], outv[1], outv[2], outv[3]);
     }
+    SRX_STAMP(6);
 }
 
 // plain sign plane <-> pair plane (stage-level entry points)
@@ -2090,6 +2254,9 @@ bool backproject_fast_eligible(int hr_rows, int hr_cols, int ch, int scale, cons
     FastW fw;
     if (w.radius != 3 || (ch != 1 && ch != 3) || hr_rows % 4 != 0 || hr_cols % 4 != 0 || !make_fast_weights(g, scale, fw))
         return false;
+    for (int i = 0; i < 22; ++i) // the kernel works with twice the weights: doubling must be exact
+        if (!(std::fabs(w.w[i]) < 0x1p100f) || (w.w[i] * 2.0f) * 0.5f != w.w[i])
+            return false;
     if (scale == 4)
         return ((size_t)(hr_rows / 4) * (hr_cols / 4) + 1) * 8 <= (1u << 24);
     return hr_rows >= 8 && hr_cols >= 8 && ((size_t)(hr_rows / 2 + 1) * (hr_cols / 2) + 4) * 4 <= (1u << 24);
@@ -2112,9 +2279,9 @@ int launch_backproject_update(const float* X, float* X_out, int hr_rows, int hr_
         const size_t ps = plane_stride_for((size_t)hr_rows * hr_cols);
         const unsigned n_tiles = (unsigned)tiles_x * tiles_y;
         const dim3 gr(xcd_grid(n_tiles)), b(SRX_B_THREADS);
-        BtvW ws = w; // weights times 2^85 (exact), see scaled_sign
+        BtvW ws = w; // twice the weights (exact, checked by backproject_fast_eligible), see half_step2
         for (int i = 0; i < kMaxBtvWeights; ++i)
-            ws.w[i] *= kBtvWeightScale;
+            ws.w[i] *= 2.0f;
 #define SRX_UPD(CHN, FT) hipLaunchKernelGGL((k_backproject_update_s4<CHN, FT>), gr, b, 0, st, X, X_out, hr_rows, hr_cols, ps, *dec_fwd, signs, K, fw, ws, tau, lambda, tiles_x, n_tiles)
         if (ch == 1 && scale == 4)
             SRX_UPD(1, 2);

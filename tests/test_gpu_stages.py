@@ -226,6 +226,41 @@ def test_backproject_update(ops, rng, rows, cols, ch, scale, n, sigma, K, lam):
     assert np.array_equal(ref, got)
 
 
+@pytest.mark.parametrize("ch,scale", [(1, 4), (3, 4), (3, 2)])
+def test_backproject_update_with_values_that_are_not_plain(ops, rng, ch, scale):
+    """NaN, infinite, huge, denormal and signed-zero pixels: diffSign of the reference compares, so a NaN
+    counts as equal (lib/src/btv_l1.cpp:138-141); the specialised kernel has to give the same regulariser as
+    the comparison-based oracle wherever the output is a number, and NaN where the oracle has NaN."""
+    rows, cols, K = 12, 40, 3
+    H, W = rows * scale, cols * scale
+    B, alpha, tau, lam = 7, 0.7, 1.3, 0.03
+    X = np.round(rng.random((H, W, ch)) * 255).astype(np.float32)
+    X[:, : W // 2] = np.round(X[:, : W // 2] / 64) * 64  # many ties
+    odd = [np.nan, np.inf, -np.inf, 3e38, -3e38, 1e30, -1e19, 1e-40, 2e-40, -1e-40, 1e-30, -0.0, 0.0, 1.5e-45]
+    for i, v in enumerate(odd):
+        X[8 + (i * 5) % (H - 16), 9 + (i * 11) % (W - 18), i % ch] = v
+    X[H // 2, W // 2 : W // 2 + 6, :] = 1e-40  # a run of equal denormals next to zeros
+    X[H // 2 + 1, W // 2 : W // 2 + 6, :] = 0.0
+    gk = oracle.gaussian_kernel(5, 0.0)
+    w = oracle.calc_btv_weights(B, alpha)
+    signs, fwd_floats, fwd_maps, signs_dev = [], [], [], []
+    for k in range(K):
+        rel = smooth_motion(rng, rows, cols, amp=2.0)
+        hr = oracle.upscale_motion(rel, scale)
+        f, _ = oracle.build_motion_maps(hr)
+        s = rng.integers(-1, 2, (rows, cols, ch)).astype(np.float32)
+        signs.append(s)
+        fwd_floats.append(f)
+        fm, _ = ops.build_maps(dev(rel), scale)
+        fwd_maps.append(fm)
+        signs_dev.append(dev(ops.pack_signs(s)))
+    with np.errstate(all="ignore"):
+        ref = _backproject_ref(X, signs, fwd_floats, scale, gk, B, w, tau, lam)
+    got = host(ops.backproject_update(dev(X), fwd_maps, signs_dev, scale, gk, B, w, tau, lam))
+    assert np.isnan(ref).sum() >= 1 and np.isinf(ref).sum() >= 2
+    assert np.array_equal(ref, got, equal_nan=True)
+
+
 @pytest.mark.parametrize("ch,border", [(1, 7), (3, 7), (3, 0), (1, 3)])
 def test_crop_convert(ops, rng, ch, border):
     X = (rng.random((40, 52, ch)) * 300 - 20).astype(np.float32)
