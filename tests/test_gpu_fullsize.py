@@ -1,6 +1,8 @@
 """Parity at the sizes of the benchmark configurations, where the CPU oracle is too slow for a full solve.
 
- * cfg1 size (320x240 grey -> 1280x960): a short solve against the oracle itself, bit-exact.
+ * cfg1 size (320x240 grey -> 1280x960): a short solve against the oracle itself, bit-exact, and the
+   configuration exactly as stated (window 9, 180 iterations) with both kernel families: sign() steps make
+   the iteration sensitive to the last bit, so the full length is run, not inferred from short solves.
  * cfg2 / cfg4 sizes (480x270 and 960x540 RGB, window 9): the specialised kernels against the generic
    kernels, bit-exact - two independent GPU implementations, the generic one pinned to the oracle by
    the small-size tests.
@@ -49,6 +51,60 @@ def test_cfg1_size_against_the_oracle():
     out, full = _solve(y, flows, 2, 0, iterations=4)
     assert np.array_equal(ref_full, full.cpu().numpy())
     assert np.array_equal(ref_out, out.cpu().numpy())
+
+
+@pytest.mark.parametrize("path", [0, 1], ids=["specialised", "generic"])
+def test_cfg1_as_stated_window_9_and_180_iterations(path):
+    """320x240 grey, temporal radius 4 (9 frames, base 4), 180 iterations, default parameters otherwise:
+    the whole solve against the oracle, bit for bit."""
+    K, rows, cols = 9, 240, 320
+    y, flows = _sequence(K, rows, cols, 1, seed=12)
+    p = oracle.BtvParams(iterations=180)
+    ref_out, ref_full = oracle.btvl1_process([f.cpu().numpy() for f in y], [f.cpu().numpy() for f in flows], 4, p,
+                                             return_full=True)
+    out, full = _solve(y, flows, 4, path, iterations=180)
+    assert np.array_equal(ref_full, full.cpu().numpy())
+    assert np.array_equal(ref_out, out.cpu().numpy())
+
+
+def test_streaming_180_iterations_rgb():
+    """A whole stream (2r + 4 frames, r = 2, RGB) at the default 180 iterations through nextFrame(), against the
+    oracle's streaming driver."""
+    from oracle import stream as ostream
+    from superresolution_amd import api, synth
+
+    rows, cols, ch, r, n = 20, 28, 3, 2, 8
+    lr, flows, _ = synth.make_sequence(n, rows, cols, ch, 4, seed=77)
+    lr_np = [f.numpy() for f in lr]
+    fl_np = [f.numpy() for f in flows]
+
+    def flow_fn():
+        state = {"i": 0}
+
+        def fn(_a, _b):
+            state["i"] += 1
+            return fl_np[state["i"] - 1]
+
+        return fn
+
+    ref = ostream.BTV_L1(flow_fn())
+    ref.params = oracle.BtvParams(iterations=180)
+    ref.temporalAreaRadius = r
+    ref.setFrameSource(ostream.ListFrameSource(lr_np))
+    sr = api.BTV_L1()
+    sr.set("iterations", 180)
+    sr.set("temporalAreaRadius", r)
+    sr.setOpticalFlow(flow_fn())
+    sr.setFrameSource(ostream.ListFrameSource(lr_np))
+    count = 0
+    while True:
+        a, b = ref.nextFrame(), sr.nextFrame()
+        if a is None or b is None:
+            assert a is None and b is None
+            break
+        assert np.array_equal(a, np.asarray(b)), f"frame {count}"
+        count += 1
+    assert count == n
 
 
 @pytest.mark.parametrize("rows,cols,iters", [(270, 480, 6), (540, 960, 4)])
