@@ -65,7 +65,8 @@ typedef struct srx_handle srx_handle;
 /* videostab::IFrameSource as used by lib/include/super_resolution.hpp:149
  * (shape visible in samples/quality_test/main.cpp:43-50): next() fills *out
  * and returns 1, or returns 0 at the end of the stream (the empty Mat). The
- * image must stay valid until the next call of next(). */
+ * image must stay valid until the next call of next() (the library has finished
+ * reading it - also from device or pinned memory - before it calls next() again). */
 typedef int (*srx_next_frame_fn)(void* user, srx_image* out);
 typedef void (*srx_reset_fn)(void* user);
 
@@ -74,6 +75,14 @@ typedef void (*srx_reset_fn)(void* user);
  * the source delivered them; the plug-in fills *flow (rows x cols, 2 channels,
  * SRX_32F, interleaved dx,dy; host or device) and returns 0 on success. */
 typedef int (*srx_flow_fn)(void* user, const srx_image* frame0, const srx_image* frame1, srx_image* flow);
+/* The two-output form calc(frame0, frame1, flow1, flow2) of the same interface
+ * (lib/include/optical_flow.hpp:44, lib/src/optical_flow.cpp:71-81): the plug-in fills two planes, flow_u and
+ * flow_v (rows x cols, 1 channel, SRX_32F each).
+ * Lifetime, both forms: the frames handed to the plug-in are valid during the call; the result images must stay
+ * valid until the plug-in is called again on this handle or the call that invoked it returns, whichever comes
+ * first (device and pinned results are read on the handle's stream, which the library waits for at those points). */
+typedef int (*srx_flow2_fn)(void* user, const srx_image* frame0, const srx_image* frame1, srx_image* flow_u,
+                            srx_image* flow_v);
 
 enum
 {
@@ -114,6 +123,7 @@ SRX_API int srx_get_double(srx_handle* h, const char* name, double* value);
  * samples/quality_test/main.cpp:267 */
 SRX_API int srx_set_flow_builtin(srx_handle* h, int kind);
 SRX_API int srx_set_flow_callback(srx_handle* h, srx_flow_fn fn, void* user);
+SRX_API int srx_set_flow_callback2(srx_handle* h, srx_flow2_fn fn, void* user);
 /* parameters of the built-in flows.  TV-L1: tau, lambda, theta, epsilon (double); nscales, warps,
  * iterations (int).  Farneback (names of lib/include/optical_flow.hpp's class Farneback): pyrScale,
  * polySigma (double); numLevels, winSize, numIters, polyN, flags (int; 0 = box window, 256 = Gaussian
@@ -192,7 +202,9 @@ SRX_API int srx_calc_btv_weights(int btv_kernel_size, double alpha, float* w);
 /* getGaussianKernel as createGaussianFilter calls it, lib/src/btv_l1.cpp:394 */
 SRX_API int srx_gaussian_kernel(int n, double sigma, float* k);
 /* Contiguous span of output frames owned by `rank` of `world`, and the range
- * of input frames (halo of `radius` on both sides, clipped) it needs. */
+ * of input frames (halo of `radius` on both sides, clipped) it needs.  With world > 1 the plan is
+ * refused (SRX_ERR_INVALID, for every rank alike) when some rank would be fed fewer than 2*radius+1
+ * frames, which the warm-up of its stream needs (lib/src/btv_l1.cpp:476-481). */
 SRX_API int srx_span_plan(int total_frames, int radius, int world, int rank, int* out_first, int* out_last,
                           int* in_first, int* in_last);
 
@@ -280,6 +292,10 @@ SRX_API int srx_process_device(srx_handle* h, const float* const* y_host, const 
  * Synchronises the stream.  No counterpart in the reference (its samples time
  * whole frames, samples/video/main.cpp:40-47). */
 SRX_API int srx_kernel_times(srx_handle* h, double* forward_ms, double* backproject_ms, long* iterations);
+/* dst = src, 16 bytes per lane, bytes a multiple of 16 (device pointers, 16-byte aligned): the plain streaming
+ * copy whose rate bench.py sets beside the kernels' as the measured ceiling of the memory system.  No
+ * counterpart in the reference. */
+SRX_API int srx_k_copy(const void* src, void* dst, size_t bytes, void* stream);
 /* Stream the handle launches on (hipStream_t), for callers that time or order work against it. */
 SRX_API void* srx_stream(srx_handle* h);
 /* Blocks until everything queued on the handle's stream has finished. */

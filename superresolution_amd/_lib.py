@@ -35,6 +35,7 @@ class SrxImage(C.Structure):
 NEXT_FRAME_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(SrxImage))
 RESET_FN = C.CFUNCTYPE(None, C.c_void_p)
 FLOW_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(SrxImage), C.POINTER(SrxImage), C.POINTER(SrxImage))
+FLOW2_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(SrxImage), C.POINTER(SrxImage), C.POINTER(SrxImage), C.POINTER(SrxImage))
 
 _vp = C.c_void_p
 _ip = C.POINTER(C.c_int)
@@ -54,6 +55,7 @@ SIGNATURES = {
     "srx_get_double": (C.c_int, [_vp, C.c_char_p, _dp]),
     "srx_set_flow_builtin": (C.c_int, [_vp, C.c_int]),
     "srx_set_flow_callback": (C.c_int, [_vp, FLOW_FN, _vp]),
+    "srx_set_flow_callback2": (C.c_int, [_vp, FLOW2_FN, _vp]),
     "srx_flow_set_int": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "srx_flow_set_double": (C.c_int, [_vp, C.c_char_p, C.c_double]),
     "srx_flow_get_int": (C.c_int, [_vp, C.c_char_p, _ip]),
@@ -88,6 +90,7 @@ SIGNATURES = {
     "srx_set_kernel_path": (C.c_int, [C.c_int]),
     "srx_get_kernel_path": (C.c_int, []),
     "srx_kernel_times": (C.c_int, [_vp, _dp, _dp, C.POINTER(C.c_long)]),
+    "srx_k_copy": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "srx_stream": (_vp, [_vp]),
     "srx_synchronize": (C.c_int, [_vp]),
 }

@@ -78,20 +78,16 @@ class DenseOpticalFlow:
     def calc(self, frame0, frame1):
         raise NotImplementedError
 
-    def calcFlowDevice(self, gray0, gray1):
-        """Built-in flow (TV-L1, or Farneback when that is set) on two CUDA float grey images; returns ((rows, cols, 2) CUDA tensor, executed iterations)."""
-        import torch
-
-        rows, cols = gray0.shape
-        flow = torch.empty((rows, cols, 2), dtype=torch.float32, device=gray0.device)
-        n = C.c_longlong()
-        torch.cuda.synchronize()
-        L.check(self._lib.srx_flow_calc_device(self._h, gray0.contiguous().data_ptr(), gray1.contiguous().data_ptr(),
-                                               rows, cols, flow.data_ptr(), C.byref(n)))
-        return flow, n.value
-
     def collectGarbage(self):
         pass
+
+
+class PlanarOpticalFlow(DenseOpticalFlow):
+    """The two-output form calc(frame0, frame1, flow1, flow2) of the same interface (lib/src/optical_flow.cpp:
+    71-81): subclass and implement calc2(frame0, frame1) -> (u, v), two (rows, cols) float32 planes."""
+
+    def calc2(self, frame0, frame1):
+        raise NotImplementedError
 
 
 class CallableFlow(DenseOpticalFlow):
@@ -122,8 +118,8 @@ class Farneback(DenseOpticalFlow):
             setattr(self, k, v)
 
 
-def _view(im: L.SrxImage):
-    """numpy (host) or torch (device) view of a library-owned image."""
+def _view(im: L.SrxImage, device: int = 0):
+    """numpy (host) or torch (device `device`) view of a library-owned image."""
     shape = (im.rows, im.cols, im.channels)
     n = im.rows * im.cols * im.channels
     if im.mem == L.SRX_MEM_HOST:
@@ -144,7 +140,7 @@ def _view(im: L.SrxImage):
         "data": (im.data, False),
         "version": 2,
     }
-    t = torch.as_tensor(d, device="cuda")
+    t = torch.as_tensor(d, device=torch.device("cuda", max(device, 0)))
     return t[:, :, 0] if im.channels == 1 else t
 
 
@@ -156,6 +152,7 @@ class BTV_L1:
         h = C.c_void_p()
         L.check(self._lib.srx_create_btvl1(device, C.byref(h)))
         self._h = h
+        self._device = device
         self._keep = []
         self._src = None
         self._flow = Farneback()  # opticalFlow = new Farneback, lib/src/btv_l1.cpp:287 (the library's default)
@@ -208,10 +205,33 @@ class BTV_L1:
             flow = CallableFlow(flow)
         self._flow = flow
         state = {"keep": []}
+        dev = self._device
+        if isinstance(flow, PlanarOpticalFlow):
+
+            def _cb2(_user, f0, f1, out_u, out_v):
+                try:
+                    u, v = flow.calc2(_view(f0.contents, dev), _view(f1.contents, dev))
+                    keep = []
+                    hu, hv = _describe(u, keep), _describe(v, keep)
+                    if hu.channels != 1 or hv.channels != 1 or hu.depth != L.SRX_32F or hv.depth != L.SRX_32F:
+                        return 1
+                    state["keep"] = keep  # valid until the next call
+                    C.memmove(out_u, C.byref(hu), C.sizeof(L.SrxImage))
+                    C.memmove(out_v, C.byref(hv), C.sizeof(L.SrxImage))
+                    return 0
+                except Exception:  # a Python exception must not unwind through C
+                    import traceback
+
+                    traceback.print_exc()
+                    return 1
+
+            self._flow_cb = L.FLOW2_FN(_cb2)
+            L.check(self._lib.srx_set_flow_callback2(self._h, self._flow_cb, None))
+            return
 
         def _cb(_user, f0, f1, out):
             try:
-                a0, a1 = _view(f0.contents), _view(f1.contents)
+                a0, a1 = _view(f0.contents, dev), _view(f1.contents, dev)
                 res = flow.calc(a0, a1)
                 keep = []
                 hdr = _describe(res, keep)
@@ -275,7 +295,7 @@ class BTV_L1:
             return None
         if not im.data:  # dry-run handle: sizes only
             return (im.rows, im.cols, im.channels)
-        return _view(im)
+        return _view(im, self._device)
 
     def drainEvents(self, max_events: int = 4096):
         buf = (C.c_int * (5 * max_events))()
@@ -299,7 +319,7 @@ class BTV_L1:
             if f0.mem == L.SRX_MEM_DEVICE:
                 import torch
 
-                out = torch.empty(shape, device="cuda",
+                out = torch.empty(shape, device=torch.device("cuda", max(self._device, 0)),
                                   dtype={L.SRX_8U: torch.uint8, L.SRX_16U: torch.uint16}.get(f0.depth, torch.float32))
             else:
                 out = np.empty(shape, {L.SRX_8U: np.uint8, L.SRX_16U: np.uint16}.get(f0.depth, np.float32))
@@ -331,7 +351,7 @@ class BTV_L1:
         rows, cols = gray0.shape
         flow = torch.empty((rows, cols, 2), dtype=torch.float32, device=gray0.device)
         n = C.c_longlong()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(gray0.device)
         L.check(self._lib.srx_flow_calc_device(self._h, gray0.contiguous().data_ptr(), gray1.contiguous().data_ptr(),
                                                rows, cols, flow.data_ptr(), C.byref(n)))
         return flow, n.value

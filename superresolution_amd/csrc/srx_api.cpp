@@ -73,6 +73,7 @@ struct srx_handle
     // optical flow plug-in
     int flow_kind = SRX_FLOW_FARNEBACK; // opticalFlow = new Farneback, lib/src/btv_l1.cpp:287
     srx_flow_fn flow_fn = nullptr;
+    srx_flow2_fn flow2_fn = nullptr; // two-output form: planar u, v
     void* flow_user = nullptr;
     Tvl1Params flow_params;
     Tvl1 tvl1;
@@ -102,7 +103,7 @@ struct srx_handle
     std::vector<uint8_t> prev_host;
     DeviceBuffer prev_dev;
     srx_image prev_hdr{};
-    DeviceBuffer staging, flow_dev, batch_out;
+    DeviceBuffer staging, flow_dev, flow_planes, batch_out;
     std::vector<DeviceBuffer> batch_frames, batch_motions;
     PinnedBuffer dst_host;
     int outputMemory = SRX_MEM_HOST;
@@ -116,6 +117,39 @@ struct srx_handle
     std::vector<uint8_t> look_host;
     DeviceBuffer look_dev, look_flow;
     srx_image look_hdr{};
+
+    // Reads of caller memory (source frames, flow plug-in results) are queued on the stream; the caller may
+    // reuse that memory at the next call-back, so the last queued read is marked by an event and waited for
+    // before the source or the plug-in is called again.
+    hipEvent_t caller_read = nullptr;
+    bool caller_read_pending = false;
+    int note_caller_reads()
+    {
+        if (dry)
+            return SRX_OK;
+        if (!caller_read)
+            SRX_HIP(hipEventCreateWithFlags(&caller_read, hipEventDisableTiming));
+        SRX_HIP(hipEventRecord(caller_read, stream));
+        caller_read_pending = true;
+        return SRX_OK;
+    }
+    int wait_caller_reads()
+    {
+        if (caller_read_pending)
+        {
+            SRX_HIP(hipEventSynchronize(caller_read));
+            caller_read_pending = false;
+        }
+        return SRX_OK;
+    }
+    int pull_frame(srx_image* f, int* got)
+    {
+        if (int rc = wait_caller_reads())
+            return rc;
+        *got = next(user, f);
+        log(SRX_EV_READ, *got ? 1 : 0);
+        return SRX_OK;
+    }
 
     int out_first = 0, out_last = -1; // first > last: unrestricted
     bool trace = false;
@@ -167,6 +201,41 @@ int srx_handle::calc_flow(const srx_image& f0, const srx_image& f1, float* dst)
     const size_t bytes = (size_t)f0.rows * f0.cols * 2 * sizeof(float);
     if (flow_kind == SRX_FLOW_CALLBACK)
     {
+        if (int rc = wait_caller_reads()) // the plug-in may reuse the buffer of its previous result
+            return rc;
+        if (flow2_fn)
+        {
+            // calc(frame0, frame1, flow1, flow2): planar u and v (lib/src/optical_flow.cpp:71-81)
+            srx_image fu{}, fv{};
+            if (flow2_fn(flow_user, &f0, &f1, &fu, &fv) != 0)
+            {
+                set_error("optical-flow plug-in reported failure");
+                return SRX_ERR_FLOW;
+            }
+            if (dry)
+                return SRX_OK;
+            const size_t px = (size_t)f0.rows * f0.cols;
+            for (const srx_image* f : {&fu, &fv})
+            {
+                if (int rc = check_image(*f, "flow plug-in result"))
+                    return rc;
+                if (f->rows != f0.rows || f->cols != f0.cols || f->channels != 1 || f->depth != SRX_32F)
+                {
+                    set_error("flow plug-in results must be rows x cols x 1 float each");
+                    return SRX_ERR_FLOW;
+                }
+            }
+            if (int rc = flow_planes.reserve(px * 2 * sizeof(float)))
+                return rc;
+            float* u = flow_planes.as<float>();
+            if (int rc = copy_to_device(fu, u, stream))
+                return rc;
+            if (int rc = copy_to_device(fv, u + px, stream))
+                return rc;
+            if (int rc = launch_merge2(u, u + px, px, dst, stream))
+                return rc;
+            return note_caller_reads();
+        }
         srx_image fl{};
         if (flow_fn(flow_user, &f0, &f1, &fl) != 0)
         {
@@ -183,7 +252,9 @@ int srx_handle::calc_flow(const srx_image& f0, const srx_image& f1, float* dst)
             return SRX_ERR_FLOW;
         }
         (void)bytes;
-        return copy_to_device(fl, dst, stream);
+        if (int rc = copy_to_device(fl, dst, stream))
+            return rc;
+        return note_caller_reads();
     }
     if (flow_kind == SRX_FLOW_TVL1 || flow_kind == SRX_FLOW_FARNEBACK)
     {
@@ -263,7 +334,7 @@ int srx_handle::add_new_frame(const srx_image& frame, bool flow_ready)
             return rc;
         prev_hdr.data = prev_dev.get();
     }
-    return SRX_OK;
+    return note_caller_reads(); // the frame's memory is the source's again at its next call
 }
 
 // Reads the next call's frame now and computes its flow on the second stream; the solve enqueued
@@ -271,8 +342,9 @@ int srx_handle::add_new_frame(const srx_image& frame, bool flow_ready)
 int srx_handle::read_ahead()
 {
     srx_image f{};
-    const int got = next(user, &f);
-    log(SRX_EV_READ, got ? 1 : 0);
+    int got = 0;
+    if (int rc = pull_frame(&f, &got))
+        return rc;
     if (!got)
     {
         look_end = true;
@@ -372,8 +444,9 @@ int srx_handle::init_impl()
     for (int t = -radius; t <= radius; ++t)
     {
         srx_image frame{};
-        const int got = next(user, &frame);
-        log(SRX_EV_READ, got ? 1 : 0);
+        int got = 0;
+        if (int rc = pull_frame(&frame, &got))
+            return rc;
         if (!got)
         {
             set_error("frame source ended during warm-up (needs 2*temporalAreaRadius+1 frames)");
@@ -401,8 +474,8 @@ int srx_handle::process_impl(srx_image* out, bool* produced)
         frame = look_hdr, got = 1, look_valid = false;
     else if (!look_end)
     {
-        got = next(user, &frame);
-        log(SRX_EV_READ, got ? 1 : 0);
+        if (int rc = pull_frame(&frame, &got))
+            return rc;
     }
     if (got)
         if (int rc = add_new_frame(frame, ahead))
@@ -508,7 +581,7 @@ SRX_API void srx_destroy(srx_handle* h)
         (void)hipStreamSynchronize(h->stream);
     }
     hipStream_t st = h->stream, st2 = h->stream2;
-    hipEvent_t ev = h->prev_ready;
+    hipEvent_t ev = h->prev_ready, ev2 = h->caller_read;
     if (st2)
         (void)hipStreamSynchronize(st2);
     const bool dry = h->dry;
@@ -519,6 +592,8 @@ SRX_API void srx_destroy(srx_handle* h)
         (void)hipStreamDestroy(st2);
     if (ev)
         (void)hipEventDestroy(ev);
+    if (ev2)
+        (void)hipEventDestroy(ev2);
 }
 
 // ---- parameters -----------------------------------------------------------
@@ -683,6 +758,7 @@ SRX_API int srx_set_flow_builtin(srx_handle* h, int kind)
     }
     h->flow_kind = kind;
     h->flow_fn = nullptr;
+    h->flow2_fn = nullptr;
     h->flow_user = nullptr;
     return SRX_OK;
 }
@@ -697,6 +773,22 @@ SRX_API int srx_set_flow_callback(srx_handle* h, srx_flow_fn fn, void* user)
     }
     h->flow_kind = SRX_FLOW_CALLBACK;
     h->flow_fn = fn;
+    h->flow2_fn = nullptr;
+    h->flow_user = user;
+    return SRX_OK;
+}
+
+SRX_API int srx_set_flow_callback2(srx_handle* h, srx_flow2_fn fn, void* user)
+{
+    SRX_NEED(h);
+    if (!fn)
+    {
+        set_error("flow callback is NULL");
+        return SRX_ERR_INVALID;
+    }
+    h->flow_kind = SRX_FLOW_CALLBACK;
+    h->flow_fn = nullptr;
+    h->flow2_fn = fn;
     h->flow_user = user;
     return SRX_OK;
 }
@@ -1060,6 +1152,16 @@ SRX_API int srx_kernel_times(srx_handle* h, double* forward_ms, double* backproj
     return SRX_OK;
 }
 
+SRX_API int srx_k_copy(const void* src, void* dst, size_t bytes, void* stream)
+{
+    if (!src || !dst || bytes % 16 != 0 || ((uintptr_t)src | (uintptr_t)dst) % 16 != 0)
+    {
+        set_error("srx_k_copy: pointers and size must be multiples of 16 bytes");
+        return SRX_ERR_INVALID;
+    }
+    return launch_copy16(src, dst, bytes, (hipStream_t)stream) ? SRX_ERR_DEVICE : SRX_OK;
+}
+
 SRX_API void* srx_stream(srx_handle* h)
 {
     return h ? (void*)h->stream : nullptr;
@@ -1123,6 +1225,22 @@ SRX_API int srx_span_plan(int total_frames, int radius, int world, int rank, int
     }
     // contiguous spans, the first (total % world) ranks get one frame more
     const int q = total_frames / world, r = total_frames % world;
+    // Every rank feeds its handle the span plus its halos, and the handle's warm-up reads 2*radius+1 frames
+    // (lib/src/btv_l1.cpp:476-481): a plan in which some rank gets fewer is refused for all ranks, so that
+    // no rank of a job starts a stream its neighbour cannot start.  The ranks at the ends of the stream have one
+    // halo only and therefore need radius+1 frames of their own, the others one.
+    if (world > 1)
+        for (int g = 0; g < world; ++g)
+        {
+            const int ga = g * q + std::min(g, r), gb = ga + q + (g < r ? 1 : 0) - 1;
+            const int fed = std::min(std::max(gb, ga) + radius, total_frames - 1) - std::max(ga - radius, 0) + 1;
+            if (gb < ga || fed < 2 * radius + 1)
+            {
+                set_error("srx_span_plan: spans too short for the temporal window (every rank needs 2*radius+1 frames "
+                          "including its halos: radius+1 own frames at the ends of the stream)");
+                return SRX_ERR_INVALID;
+            }
+        }
     const int a = rank * q + std::min(rank, r);
     const int b = a + q + (rank < r ? 1 : 0) - 1; // may be a-1 (empty span) when world > total
     if (out_first)

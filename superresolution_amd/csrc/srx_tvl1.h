@@ -47,5 +47,9 @@ int launch_to_gray(const void* raw, size_t px, int ch, int depth, float* gray, h
 
 // interleaved (u,v) -> two planes
 int launch_split2(const float* uv, size_t count, float* u, float* v, hipStream_t st);
+// two planes -> interleaved (u,v)
+int launch_merge2(const float* u, const float* v, size_t count, float* uv, hipStream_t st);
+// dst[0 .. bytes) = src[0 .. bytes), bytes a multiple of 16, both 16-byte aligned (bandwidth reference)
+int launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t st);
 
 } // namespace srx

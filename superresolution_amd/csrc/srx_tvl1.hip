@@ -18,6 +18,21 @@ __global__ void k_split2(const float2* __restrict__ uv, size_t count, float* __r
     v[e] = f.y;
 }
 
+__global__ void k_merge2(const float* __restrict__ u, const float* __restrict__ v, size_t count, float2* __restrict__ uv)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < count)
+        uv[e] = make_float2(u[e], v[e]);
+}
+
+// plain streaming copy, 16 bytes per lane: what the memory system gives a kernel that only moves bytes
+__global__ __launch_bounds__(256) void k_copy16(const float4* __restrict__ src, float4* __restrict__ dst, size_t count)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += stride)
+        dst[e] = src[e];
+}
+
 int bad_name(const std::string& n)
 {
     set_error("unknown flow parameter: " + n);
@@ -32,6 +47,23 @@ int launch_split2(const float* uv, size_t count, float* u, float* v, hipStream_t
                        v);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "split2");
+}
+
+int launch_merge2(const float* u, const float* v, size_t count, float* uv, hipStream_t st)
+{
+    const int bs = 256;
+    hipLaunchKernelGGL(k_merge2, dim3((unsigned)((count + bs - 1) / bs)), dim3(bs), 0, st, u, v, count, (float2*)uv);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "merge2");
+}
+
+int launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t st)
+{
+    const size_t count = bytes / 16;
+    const unsigned blocks = (unsigned)std::min<size_t>((count + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_copy16, dim3(blocks), dim3(256), 0, st, (const float4*)src, (float4*)dst, count);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "copy16");
 }
 
 int tvl1_set_int(Tvl1Params& p, const std::string& n, int v)
@@ -561,14 +593,6 @@ __global__ void k_upsample_flow(const float* __restrict__ s1, const float* __res
         const float h1 = last ? R1[scols - 1] : R1[sx] * a0 + R1[sx + 1] * a1;
         d2[o] = (h0 * b0 + h1 * b1) * 2.0f;
     }
-}
-
-__global__ void k_merge2(const float* __restrict__ u, const float* __restrict__ v, size_t count,
-                         float2* __restrict__ uv)
-{
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < count)
-        uv[e] = make_float2(u[e], v[e]);
 }
 
 inline dim3 grid2(int cols, int rows, dim3 b)

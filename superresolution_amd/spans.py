@@ -31,7 +31,9 @@ def exchange_halo(own: Sequence[torch.Tensor], radius: int, rank: Optional[int] 
                   group=None) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
     """Swap span-boundary frames with the neighbouring ranks.
 
-    `own` holds this rank's frames in stream order (all ranks: same shape and dtype, at least `radius` frames).
+    `own` holds this rank's frames in stream order (all ranks: same shape and dtype; at least `radius` frames,
+    and `radius` + 1 on the first and the last rank, which have one halo only and whose streams otherwise could
+    not warm up - `span_plan` refuses such partitions).
     Returns (left_halo, right_halo): the last `radius` frames of rank-1 and the first `radius` frames of rank+1
     (empty lists at the ends of the stream).  Point-to-point only; no collective touches the data path.
     """
@@ -39,8 +41,9 @@ def exchange_halo(own: Sequence[torch.Tensor], radius: int, rank: Optional[int] 
     world = dist.get_world_size(group) if world is None else world
     if radius == 0 or world == 1:
         return [], []
-    if len(own) < radius:
-        raise ValueError("every span must hold at least `radius` frames")
+    edge = rank == 0 or rank == world - 1
+    if len(own) < radius + (1 if edge else 0):
+        raise ValueError("every span must hold at least `radius` frames, the first and the last `radius` + 1")
     left = [torch.empty_like(own[0]) for _ in range(radius)] if rank > 0 else []
     right = [torch.empty_like(own[0]) for _ in range(radius)] if rank < world - 1 else []
     ops = []

@@ -189,6 +189,110 @@ def test_streaming_matches_oracle(n_frames, r, ch, mem):
     assert mine == o.log
 
 
+@pytest.mark.parametrize("kind", ["device", "pinned"])
+def test_source_and_flow_plugin_that_reuse_one_buffer(kind):
+    """A source that refills ONE device (or pinned host) buffer per call, and a flow plug-in that does the same
+    with its result: the library reads such memory on its stream, so it has to finish reading before it calls
+    the source / the plug-in again (the image 'must stay valid until the next call of next()').  Larger frames
+    than elsewhere, so that a copy still in flight would be caught."""
+    import torch
+    from superresolution_amd import api, synth, _lib as L
+
+    n_frames, rows, cols, ch, r, T = 9, 96, 128, 3, 2, 3
+    lr, flows, _ = synth.make_sequence(n_frames, rows, cols, ch, 4, seed=91)
+    lr_np = [f.numpy() for f in lr]
+    fl_np = [f.numpy() for f in flows]
+    o = ostream.BTV_L1(TrueFlow(fl_np))
+    o.params = oracle.BtvParams(iterations=T)
+    o.temporalAreaRadius = r
+    o.setFrameSource(ostream.ListFrameSource(lr_np))
+    ref = []
+    while (f := o.nextFrame()) is not None:
+        ref.append(f.copy())
+
+    if kind == "device":
+        fbuf = torch.empty((rows, cols, ch), dtype=torch.uint8, device="cuda")
+        mbuf = torch.empty((rows, cols, 2), dtype=torch.float32, device="cuda")
+    else:
+        fbuf = torch.empty((rows, cols, ch), dtype=torch.uint8).pin_memory()
+        mbuf = torch.empty((rows, cols, 2), dtype=torch.float32).pin_memory()
+
+    class OneBufferSource:
+        def __init__(self):
+            self.i = 0
+
+        def reset(self):
+            self.i = 0
+
+        def nextFrame(self):
+            if self.i >= n_frames:
+                return None
+            fbuf.copy_(torch.from_numpy(lr_np[self.i]))  # overwrites the frame handed out by the previous call
+            if kind == "device":
+                torch.cuda.synchronize()
+            self.i += 1
+            return fbuf
+
+    class OneBufferFlow:
+        def __init__(self):
+            self.i = 0
+
+        def __call__(self, a, b):
+            mbuf.copy_(torch.from_numpy(fl_np[self.i]))
+            if kind == "device":
+                torch.cuda.synchronize()
+            self.i += 1
+            return mbuf
+
+    sr = api.BTV_L1()
+    sr.set("iterations", T)
+    sr.set("temporalAreaRadius", r)
+    sr.setOpticalFlow(OneBufferFlow())
+    sr.setFrameSource(OneBufferSource())
+    got = []
+    while (f := sr.nextFrame()) is not None:
+        got.append(np.array(f, copy=True))
+    assert len(got) == len(ref)
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+
+
+def test_two_output_flow_plugin():
+    """calc(frame0, frame1, flow1, flow2): a plug-in that delivers planar u and v (lib/src/optical_flow.cpp:
+    71-81) gives the same stream as one that delivers the interleaved field."""
+    from superresolution_amd import api, synth
+
+    n_frames, rows, cols, ch, r, T = 6, 16, 20, 3, 1, 5
+    lr, flows, _ = synth.make_sequence(n_frames, rows, cols, ch, 4, seed=93)
+    lr_np = [f.numpy() for f in lr]
+    fl_np = [f.numpy() for f in flows]
+
+    class Planar(api.PlanarOpticalFlow):
+        def __init__(self):
+            self.i = 0
+
+        def calc2(self, a, b):
+            f = fl_np[self.i]
+            self.i += 1
+            return np.ascontiguousarray(f[:, :, 0]), np.ascontiguousarray(f[:, :, 1])
+
+    def run(flow):
+        sr = api.BTV_L1()
+        sr.set("iterations", T)
+        sr.set("temporalAreaRadius", r)
+        sr.setOpticalFlow(flow)
+        sr.setFrameSource(ostream.ListFrameSource(lr_np))
+        out = []
+        while (f := sr.nextFrame()) is not None:
+            out.append(np.array(f, copy=True))
+        return out
+
+    a, b = run(TrueFlow(fl_np)), run(Planar())
+    assert len(a) == len(b) == n_frames
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
 def test_batch_process_8u_host(rng):
     """srx_process on 8-bit host frames with forward motions: output is 8 bit, cropped by btvKernelSize."""
     from superresolution_amd import api, synth

@@ -97,7 +97,7 @@ def test_host_kernels_tables():
 
 
 def test_span_plan_covers_stream_once():
-    for total, world, r in [(100, 8, 4), (17, 4, 2), (8, 8, 1), (30, 1, 4), (33, 2, 8)]:
+    for total, world, r in [(100, 8, 4), (17, 4, 2), (16, 8, 1), (30, 1, 4), (33, 2, 8), (40, 8, 4)]:
         seen = []
         for rank in range(world):
             a, b, i0, i1 = spans.span_plan(total, r, world, rank)
@@ -107,6 +107,35 @@ def test_span_plan_covers_stream_once():
         assert seen == list(range(total))
     with pytest.raises(L.SrxError):
         spans.span_plan(10, 4, 2, 2)
+    # The ranks at the ends of the stream have one halo only: with `radius` frames of their own their handles
+    # could not warm up (2 * radius + 1 reads), so the plan is refused for every rank alike; radius + 1 is enough.
+    for rank in range(8):
+        with pytest.raises(L.SrxError):
+            spans.span_plan(32, 4, 8, rank)
+        spans.span_plan(40, 4, 8, rank)
+    with pytest.raises(L.SrxError):
+        spans.span_plan(8, 1, 8, 3)
+
+
+def test_edge_spans_of_radius_plus_one_frames_stream_and_shorter_ones_cannot():
+    """Dry-run handles fed as a job of 8 ranks would feed them: spans of radius + 1 own frames warm up on every
+    rank; a rank at the end of the stream with only `radius` own frames runs out of frames in its warm-up."""
+    r = 4
+
+    def run(own, left, right):
+        sr = api.BTV_L1(-1)
+        sr.set("temporalAreaRadius", r)
+        sr.setOpticalFlow(lambda a, b: np.zeros((6, 8, 2), np.float32))
+        f = [np.zeros((6, 8, 3), np.uint8)] * (left + own + right)
+        spans.configure_span(sr, f[:left], f[left:left + own], f[left + own:])
+        n = 0
+        while sr.nextFrame() is not None:
+            n += 1
+        return n
+
+    assert run(r + 1, 0, r) == r + 1 and run(r + 1, r, r) == r + 1 and run(r + 1, r, 0) == r + 1
+    with pytest.raises(L.SrxError):
+        run(r, 0, r)
 
 
 def _events(sr):
