@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
 """Throughput of the BTV-L1 super-resolution hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg2|cfg1|cfg5|tvl1]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One step = one steady-state SuperResolution::nextFrame() on one GPU: one new
-low-resolution frame enters the ring, its flow is attached, one output frame is
-solved (180 BTV-L1 iterations over a 2*4+1 frame window) and returned as 8-bit.
-With read-ahead (the default here, --no-read-ahead turns it off) the frame that
-enters and its flow belong to the next call: they are fetched while this call's
-solve runs; the work per step is the same.
-Workload (the configuration the headline metric is quoted on): 960x540 RGB ->
-3840x2160, scale 4, temporalAreaRadius 4.  Inputs are synthetic
-(superresolution_amd/synth.py), 8-bit, resident in HBM before the timed region.
+With --gpus N > 1 and no WORLD_SIZE in the environment, this process starts the N ranks itself
+(`python -m torch.distributed.run`, child processes, before anything here touches a GPU) and exits with
+their status.  A rank whose WORLD_SIZE differs from --gpus refuses to run.
 
-Multi-GPU: the stream is cut into contiguous spans of output frames, one per
-rank (weak scaling: every rank solves `steps` frames); neighbouring ranks swap
-the temporalAreaRadius boundary frames point to point before the timed region.
-No collective sits on the data path.
+One step = one steady-state SuperResolution::nextFrame() on one GPU: one new low-resolution frame enters
+the ring, its flow is attached, one output frame is solved (180 BTV-L1 iterations over a 2*4+1 frame
+window) and returned as 8-bit.  With read-ahead (the default here, --no-read-ahead turns it off) the frame
+that enters and its flow belong to the next call: they are fetched while this call's solve runs; the work
+per step is the same.
+Default workload (the configuration the headline metric is quoted on, configs[3]): 960x540 RGB ->
+3840x2160, scale 4, temporalAreaRadius 4.  Inputs are synthetic (superresolution_amd/synth.py), 8-bit,
+resident in HBM before the timed region.
+
+Multi-GPU: the stream is cut into contiguous spans of output frames, one per rank (weak scaling: every
+rank solves `steps` frames); neighbouring ranks swap the temporalAreaRadius boundary frames point to
+point before the timed region.  No collective sits on the data path.  `value` is the steady-state rate;
+`config.span_inclusive` is the rate with every rank's first call (the ring warm-up: r+2 solves on the rank
+that holds the start of the stream, fewer on the others) and the warm-up steps inside the clock.
+
+--workload tvl1 measures the flow stage alone (configs[2]): 1920x1080 grey frame pairs, 5 scales x 5 warps
+x 300 inner iterations at most, pairs sharded over the ranks (independent, no exchange).
 
 Prints one JSON line on rank 0.
 """
@@ -26,17 +33,23 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+METRIC = "output Mpix/s, BTV-L1 4x 960x540->4K, 1/2/4/8 GPUs; % HBM roofline"
+
+# rows, cols, channels, scale, radius, which entry of BASELINE.json's configs
+WORKLOADS = {
+    "cfg1": (240, 320, 1, 4, 4, "configs[0]"),
+    "cfg2": (270, 480, 3, 4, 4, "configs[1]"),
+    "cfg4": (540, 960, 3, 4, 4, "configs[3]"),
+    "cfg5": (1080, 1920, 3, 2, 8, "configs[4]"),
+}
 
 
 def parse():
@@ -44,11 +57,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--rows", type=int, default=540, help="LR rows")
-    ap.add_argument("--cols", type=int, default=960, help="LR cols")
-    ap.add_argument("--channels", type=int, default=3)
-    ap.add_argument("--scale", type=int, default=4)
-    ap.add_argument("--radius", type=int, default=4)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["tvl1"], default="cfg4")
+    ap.add_argument("--rows", type=int, default=None, help="LR rows (overrides the workload's)")
+    ap.add_argument("--cols", type=int, default=None, help="LR cols")
+    ap.add_argument("--channels", type=int, default=None)
+    ap.add_argument("--scale", type=int, default=None)
+    ap.add_argument("--radius", type=int, default=None)
     ap.add_argument("--iterations", type=int, default=180)
     ap.add_argument("--flow", choices=["synthetic", "tvl1", "farneback"], default="tvl1",
                     help="motion stage: exact synthetic motion resident in HBM, the built-in TV-L1 flow, or the "
@@ -62,7 +76,39 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not bracket the solver kernels with HIP events (the roofline object is then left out)")
     ap.add_argument("--cpu-iters", type=int, default=12, help="iterations of the CPU sample solve")
-    return ap.parse_args()
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when this process starts the ranks")
+    a = ap.parse_args()
+    if a.workload != "tvl1":
+        w = WORKLOADS[a.workload]
+        a.default_shape = all(v is None for v in (a.rows, a.cols, a.channels, a.scale, a.radius))
+        a.rows = w[0] if a.rows is None else a.rows
+        a.cols = w[1] if a.cols is None else a.cols
+        a.channels = w[2] if a.channels is None else a.channels
+        a.scale = w[3] if a.scale is None else a.scale
+        a.radius = w[4] if a.radius is None else a.radius
+        a.config_name = w[5] if a.default_shape else "other configuration"
+    else:
+        a.rows = 1080 if a.rows is None else a.rows
+        a.cols = 1920 if a.cols is None else a.cols
+    return a
+
+
+def launch_ranks(args) -> int:
+    """Start args.gpus ranks of this script as child processes (one per GPU, RCCL) and return their status.
+    Nothing in this process has touched a GPU yet; the children are fresh interpreters."""
+    import socket
+
+    port = args.master_port
+    if not port:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def algorithmic_bytes(P, C, K, s):
@@ -78,15 +124,14 @@ def measured_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/*_traffic.json, written by
     scripts/pmc_traffic.py on the same workload), or None."""
     import glob
-    here = os.path.dirname(os.path.abspath(__file__))
-    files = sorted(glob.glob(os.path.join(here, "profiles", "*_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
     if not files:
         return None, None
     try:
         d = json.load(open(files[-1]))
         for name, v in d["kernels"].items():
             if name.startswith(kernel):
-                return v["traffic_bytes_per_launch"], os.path.relpath(files[-1], here)
+                return v["traffic_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
     except (OSError, ValueError, KeyError):
         pass
     return None, None
@@ -96,6 +141,7 @@ def cpu_baseline(args, lr_u8, flows, base):
     """The unfused restatement of the reference CPU path (oracle/, OpenMP over rows) on one window of the same
     workload, for a bounded number of iterations, scaled to the full iteration count; at all host threads the
     process may use and, on a shorter sample, at one thread."""
+    import numpy as np
     import oracle
 
     y = [f.cpu().numpy().astype(np.float32) for f in lr_u8]
@@ -134,54 +180,104 @@ def cpu_baseline(args, lr_u8, flows, base):
     return out
 
 
-def copy_ceiling_gbs(dev) -> float:
-    """Read + write rate of a plain device-to-device copy of 1 GiB (outside the timed region): what a kernel
-    that only streams can reach on this GPU, to set beside the 8 TB/s spec peak."""
+def copy_ceilings(dev):
+    """Read + write rate of plain device-to-device copies of 1 GiB (outside the timed region): the library's own
+    16-bytes-per-lane copy kernel (srx_k_copy) and torch's copy_.  What a kernel that only streams reaches on
+    this GPU, to set beside the 8 TB/s spec peak."""
+    import torch
+    from superresolution_amd import _lib as L
+
     n = 1 << 28
     src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
     dst = torch.empty_like(src)
-    for _ in range(2):
-        dst.copy_(src)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 5
-    e0.record()
-    for _ in range(reps):
-        dst.copy_(src)
-    e1.record()
-    torch.cuda.synchronize()
-    return 2.0 * 4 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    lib = L.lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    out = {}
+    for name, fn in (("own_float4_kernel", lambda: L.check(lib.srx_k_copy(src.data_ptr(), dst.data_ptr(), 4 * n, st))),
+                     ("torch_copy", lambda: dst.copy_(src))):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        out[name] = 2.0 * 4 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    return out
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # SRX_BENCH_REHEARSE=1: all ranks share GPU 0 and talk over gloo with host copies of the halo - a way to
-    # walk the multi-rank code on a one-GPU box; its numbers mean nothing.
-    rehearse = os.environ.get("SRX_BENCH_REHEARSE") == "1"
-    if rehearse:
-        local_rank = 0
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
-            dist.init_process_group("gloo")
+class Ranks:
+    """World bookkeeping of one rank: RCCL on one GPU per rank; SRX_BENCH_REHEARSE=1: all ranks share GPU 0 and
+    talk over gloo with host copies of the halo; SRX_BENCH_REHEARSE=dry: no GPU at all, dry-run handles (host
+    bookkeeping only) - ways to walk the multi-rank code where there is one GPU or none; their numbers mean
+    nothing."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        mode = os.environ.get("SRX_BENCH_REHEARSE", "")
+        self.rehearse = mode in ("1", "dry")
+        self.dry = mode == "dry"
+        if self.world != args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {self.world}: refusing to report a line whose "
+                  f"n_gpus differs from what was asked for", file=sys.stderr)
+            sys.exit(2)
+        if self.rehearse:
+            self.local_rank = 0
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.rehearse:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+        if self.dry:
+            self.dev = torch.device("cpu")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+            torch.cuda.set_device(self.local_rank)
+            self.dev = torch.device("cuda", self.local_rank)
+        self.dist, self.torch = dist, torch
 
+    def sync(self):
+        if not self.dry:
+            self.torch.cuda.synchronize(self.dev)
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max_over_ranks(self, seconds: float) -> float:
+        if self.world == 1:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device="cpu" if self.rehearse else self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def finish(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def bench_solver(args):
+    R = Ranks(args)
+    torch = R.torch
     from superresolution_amd import api, spans, synth, _lib as L
 
     r, s = args.radius, args.scale
+    world, rank, dev = R.world, R.rank, R.dev
     # Calls: one set-up call (ring warm-up: 2r+2 reads), then W warm-up and K timed steady-state steps with one
     # read, one flow and one solve each.  The solve of a call runs r+1 frames ahead of the output it returns, so
     # a span of W + K + r + 2 owned frames keeps every timed solve inside the span with a full window.
-    read_ahead = args.flow != "synthetic" and not args.no_read_ahead
+    read_ahead = args.flow != "synthetic" and not args.no_read_ahead and not R.dry
     n_own = args.warmup + args.steps + r + 2 + (1 if read_ahead else 0)  # read-ahead pulls one frame more
     total = n_own * world
-    a = rank * n_own
+    a, b, in_first, in_last = spans.span_plan(total, r, world, rank)
+    assert b - a + 1 == n_own
     cams = synth.camera_path(total + 2 * r + 2, seed=1234)
 
     def frame(t):
@@ -189,18 +285,20 @@ def main():
         return synth.degrade(hr, s)
 
     own = [frame(t) for t in range(a, a + n_own)]
+    halo_ms = 0.0
+    left, right = [], []
     if world > 1:
-        torch.cuda.synchronize()
+        R.sync()
         t0 = time.perf_counter()
-        if rehearse:
+        if R.rehearse and not R.dry:
             left, right = spans.exchange_halo([f.cpu() for f in own], r, rank, world)
             left, right = [f.to(dev) for f in left], [f.to(dev) for f in right]
         else:
             left, right = spans.exchange_halo(own, r, rank, world)
-        torch.cuda.synchronize()
+        if not R.dry:
+            torch.cuda.synchronize(dev)
         halo_ms = (time.perf_counter() - t0) * 1e3
-    else:
-        left, right, halo_ms = [], [], 0.0
+        assert len(left) == a - in_first and len(right) == in_last - b
     if rank == world - 1:
         # the stream continues past the benchmarked frames, so that every timed step sees a full window
         right = [frame(t) for t in range(a + n_own, a + n_own + r)]
@@ -209,15 +307,15 @@ def main():
     flows = [synth.true_forward_flow(cams[first + i], cams[first + i + 1], args.rows, args.cols, s, dev)
              for i in range(len(frames) - 1)]
 
-    sr = api.BTV_L1(local_rank)
+    sr = api.BTV_L1(-1 if R.dry else R.local_rank)
     sr.set("scale", s)
     sr.set("iterations", args.iterations)
     sr.set("temporalAreaRadius", r)
     sr.set("outputMemory", L.SRX_MEM_HOST if args.host_io else L.SRX_MEM_DEVICE)
     sr.set("readAhead", 1 if read_ahead else 0)
-    if args.flow == "tvl1":
+    if args.flow == "tvl1" and not R.dry:
         sr.setOpticalFlow(api.DualTVL1())
-    elif args.flow == "farneback":
+    elif args.flow == "farneback" and not R.dry:
         sr.setOpticalFlow(api.Farneback())
     else:
         counter = {"i": 0}
@@ -225,10 +323,10 @@ def main():
         def flow_cb(_f0, _f1):
             f = flows[counter["i"]]
             counter["i"] += 1
-            return f
+            return f.numpy() if R.dry else f
 
         sr.setOpticalFlow(flow_cb)
-    if args.host_io:
+    if args.host_io or R.dry:
         left, own, right = ([f.cpu().numpy() for f in v] for v in (left, own, right))
     spans.configure_span(sr, left, own, right)
 
@@ -238,56 +336,39 @@ def main():
             raise RuntimeError("stream ended inside the benchmark")
         return out
 
+    R.sync()
+    t_span0 = time.perf_counter()
     step()  # ring warm-up: 2r+2 reads and the first solves (not a steady-state step)
     for _ in range(args.warmup):
         step()
-    sr.set("kernelTiming", 0 if args.no_kernel_timing else 1)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    timing = not args.no_kernel_timing and not R.dry
+    sr.set("kernelTiming", 1 if timing else 0)
+    R.sync()
     t0 = time.perf_counter()
     step_ms = []
     for _ in range(args.steps):
         ts = time.perf_counter()
-        out = step()
+        step()
         step_ms.append((time.perf_counter() - ts) * 1e3)
-    sr.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    fwd_ms, bwd_ms, n_it = sr.kernelTimes()
+    if not R.dry:
+        sr.synchronize()
+    R.sync()
+    t1 = time.perf_counter()
+    elapsed, span_elapsed = t1 - t0, t1 - t_span0
+    fwd_ms, bwd_ms, n_it = sr.kernelTimes() if timing else (0.0, 0.0, 0)
     sr.set("kernelTiming", 0)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = R.max_over_ranks(elapsed)
+    span_elapsed = R.max_over_ranks(span_elapsed)
 
     if rank == 0:
         P = args.rows * s * args.cols * s
         K = 2 * r + 1
         mpix = P / 1e6
         bytes_fwd, bytes_bwd = algorithmic_bytes(P, args.channels, K, s)
-        bwd_launch_s = max(bwd_ms / max(n_it, 1) / 1e3, 1e-12)
-        fwd_launch_s = max(fwd_ms / max(n_it, 1) / 1e3, 1e-12)
-        default_workload = (args.rows, args.cols, args.channels, s, r) == (540, 960, 3, 4, 4)
-        kernels = {}
-        # which kernels the library picks for this scale (default parameters otherwise)
-        fwd_name = {4: "k_forward_sign_lds", 2: "k_forward_sign_s2"}.get(s, "k_forward_sign_tile")
-        bwd_name = {4: "k_backproject_update_s4", 2: "k_backproject_update_s4"}.get(s, "k_backproject_update")
-        for name, what, nbytes, secs in (
-                (fwd_name, "sign(y_k - D H M_k X) of all window frames", bytes_fwd, fwd_launch_s),
-                (bwd_name, "back-projection of all window frames + BTV + update", bytes_bwd, bwd_launch_s)):
-            traffic, traffic_src = measured_traffic(name) if default_workload else (None, None)
-            kernels[name] = {"kernel": f"{name} ({what})", "achieved": nbytes / secs / 1e9, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": nbytes / secs / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                             "traffic_source": traffic_src, "algorithmic_bytes_per_launch": nbytes,
-                             "avg_launch_us": secs * 1e6}
-        # the dominant kernel is the one the solver spends more time in
-        dominant = fwd_name if fwd_launch_s >= bwd_launch_s else bwd_name
-        other = bwd_name if dominant == fwd_name else fwd_name
+        headline_shape = args.config_name == "configs[3]"
+        span_outputs = 1 + args.warmup + args.steps
         line = {
-            "metric": "output Mpix/s, BTV-L1 4x 960x540->4K, 1/2/4/8 GPUs; % HBM roofline",
+            "metric": METRIC,
             "value": world * args.steps * mpix / elapsed,
             "unit": "Mpix/s",
             "n_gpus": world,
@@ -300,41 +381,169 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{'configs[3]' if default_workload else 'other configuration'}: {args.cols}x{args.rows} {'RGB' if args.channels == 3 else 'gray'} -> "
+                "workload": f"{args.config_name}: {args.cols}x{args.rows} {'RGB' if args.channels == 3 else 'gray'} -> "
                             f"{args.cols * s}x{args.rows * s}, {s}x BTV-L1, {args.iterations} iterations, "
                             f"temporalAreaRadius {r} (window {K}), streaming nextFrame(), motion: "
-                            + {"tvl1": "built-in TV-L1 flow", "farneback": "built-in Farneback flow"}.get(
-                                args.flow, "exact synthetic flow resident in HBM"),
+                            + ("exact synthetic flow (dry run)" if R.dry else
+                               {"tvl1": "built-in TV-L1 flow", "farneback": "built-in Farneback flow"}.get(
+                                   args.flow, "exact synthetic flow resident in HBM")),
                 "frames_per_gpu": args.steps,
                 "io": "host frames in, host frames out (PCIe inclusive)" if args.host_io else "frames resident in HBM",
                 "read_ahead": read_ahead,
                 "partition": "contiguous span of output frames per GPU, halo of r LR frames swapped point to point",
                 "halo_exchange_ms": round(halo_ms, 3),
+                "span_inclusive": {
+                    "value": world * span_outputs * mpix / span_elapsed, "unit": "Mpix/s",
+                    "ms": round(span_elapsed * 1e3, 2), "outputs_per_gpu": span_outputs,
+                    "what": "every rank's first call (ring warm-up; r+2 solves on the rank that holds the start of the "
+                            "stream) and the warm-up steps inside the clock, max over ranks"},
                 "step_ms": [round(v, 2) for v in step_ms],
                 "delivered_frame": f"{args.cols * s - 14}x{args.rows * s - 14} (cropped by btvKernelSize)",
             },
-            "roofline": dict(
+        }
+        if R.rehearse:
+            line["config"]["rehearsal"] = "dry-run handles on CPU over gloo" if R.dry else "all ranks on GPU 0 over gloo"
+        if timing:
+            bwd_launch_s = max(bwd_ms / max(n_it, 1) / 1e3, 1e-12)
+            fwd_launch_s = max(fwd_ms / max(n_it, 1) / 1e3, 1e-12)
+            kernels = {}
+            # which kernels the library picks for this scale (default parameters otherwise)
+            fwd_name = {4: "k_forward_sign_lds", 2: "k_forward_sign_s2"}.get(s, "k_forward_sign_tile")
+            bwd_name = {4: "k_backproject_update_s4", 2: "k_backproject_update_s4"}.get(s, "k_backproject_update")
+            for name, what, nbytes, secs in (
+                    (fwd_name, "sign(y_k - D H M_k X) of all window frames", bytes_fwd, fwd_launch_s),
+                    (bwd_name, "back-projection of all window frames + BTV + update", bytes_bwd, bwd_launch_s)):
+                traffic, traffic_src = measured_traffic(name) if headline_shape else (None, None)
+                kernels[name] = {"kernel": f"{name} ({what})", "achieved": nbytes / secs / 1e9, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": nbytes / secs / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                                 "traffic_source": traffic_src, "algorithmic_bytes_per_launch": nbytes,
+                                 "avg_launch_us": secs * 1e6}
+            # the dominant kernel is the one the solver spends more time in
+            dominant = fwd_name if fwd_launch_s >= bwd_launch_s else bwd_name
+            other = bwd_name if dominant == fwd_name else fwd_name
+            line["roofline"] = dict(
                 {"bound": "hbm"}, **kernels[dominant],
                 other_kernel=kernels[other],
                 iteration={"algorithmic_bytes": bytes_fwd + bytes_bwd,
                            "achieved": (bytes_fwd + bytes_bwd) / (fwd_launch_s + bwd_launch_s) / 1e9,
-                           "frac": (bytes_fwd + bytes_bwd) / (fwd_launch_s + bwd_launch_s) / 1e9 / HBM_PEAK_GBS}),
-        }
-        if args.no_kernel_timing:
-            del line["roofline"]
-        else:
-            ceiling = copy_ceiling_gbs(dev)
-            line["roofline"]["copy_ceiling"] = {"value": round(ceiling, 1), "unit": "GB/s",
-                                                "what": "device-to-device copy of 1 GiB, read + write bytes",
-                                                "frac_of_ceiling": line["roofline"]["achieved"] / ceiling}
-        if world == 1 and not args.no_cpu_baseline:
+                           "frac": (bytes_fwd + bytes_bwd) / (fwd_launch_s + bwd_launch_s) / 1e9 / HBM_PEAK_GBS},
+                step={"algorithmic_bytes": (bytes_fwd + bytes_bwd) * args.iterations,
+                      "frac": (bytes_fwd + bytes_bwd) * args.iterations / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                      "what": "solver bytes of one output frame over the whole step time (flow, map building, "
+                              "crop and launch gaps included)"})
+            ceil = copy_ceilings(dev)
+            line["roofline"]["copy_ceiling"] = {
+                "value": round(ceil["own_float4_kernel"], 1), "unit": "GB/s",
+                "what": "device-to-device copy of 1 GiB by the library's own float4 copy kernel, read + write bytes",
+                "torch_copy": round(ceil["torch_copy"], 1),
+                "frac_of_ceiling": line["roofline"]["achieved"] / ceil["own_float4_kernel"]}
+        if world == 1 and not args.no_cpu_baseline and not R.dry:
             base = min(r, len(frames) - 1)
             win = frames[:2 * r + 1]
             line["cpu_baseline"] = cpu_baseline(args, win, flows[:2 * r], base)
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    R.finish()
+
+
+def bench_tvl1(args):
+    """The flow stage alone: pairs of consecutive grey frames of the synthetic clip, sharded over the ranks."""
+    R = Ranks(args)
+    torch = R.torch
+    if R.dry:
+        print("bench.py: the tvl1 workload needs a GPU", file=sys.stderr)
+        sys.exit(2)
+    import numpy as np
+    from superresolution_amd import api, spans, synth, _lib as L
+
+    rows, cols, dev = args.rows, args.cols, R.dev
+    n_pairs = args.warmup + args.steps
+    # pair t = frames (t, t + 1) of the clip; ranks own disjoint contiguous ranges of pairs
+    first, last = spans.pair_shard(R.world * n_pairs, R.world, R.rank)
+    assert last - first == n_pairs
+    cams = synth.camera_path(R.world * n_pairs + 1, seed=4321)
+    gray = [synth.ground_truth_frame(cams[first + t], rows, cols, 1, 4321, dev)[:, :, 0].to(torch.float32).contiguous()
+            for t in range(n_pairs + 1)]
+    sr = api.BTV_L1(R.local_rank)
+    sr.setOpticalFlow(api.DualTVL1())
+    lib = L.lib()
+    import ctypes as C
+
+    def pair(t):
+        _flow, iters = sr.calcFlowDevice(gray[t], gray[t + 1])
+        sr.synchronize()
+        w = C.c_longlong()
+        L.check(lib.srx_flow_pixel_iterations(sr.handle, C.byref(w)))
+        return iters, w.value
+
+    for t in range(args.warmup):
+        pair(t)
+    R.sync()
+    t0 = time.perf_counter()
+    iters, work, step_ms = [], [], []
+    for t in range(args.warmup, n_pairs):
+        ts = time.perf_counter()
+        i, w = pair(t)
+        step_ms.append((time.perf_counter() - ts) * 1e3)
+        iters.append(i)
+        work.append(w)
+    R.sync()
+    elapsed = R.max_over_ranks(time.perf_counter() - t0)
+    if R.rank == 0:
+        bytes_pair = 64.0 * float(np.mean(work))  # 16 floats read or written per pixel and inner iteration
+        per_pair_s = elapsed / args.steps
+        line = {
+            "metric": "TV-L1 flow stage, 1920x1080 grey frame pairs per second",
+            "value": R.world * args.steps / elapsed,
+            "unit": "pairs/s",
+            "n_gpus": R.world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": per_pair_s * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"configs[2]: TV-L1 dual optical flow standalone on {cols}x{rows} grey frame pairs, 5 scales x "
+                            f"5 warps x 300 inner iterations at most (stops per level and warp at epsilon 0.01)",
+                "partition": "frame pairs sharded over the ranks, no exchange",
+                "executed_inner_iterations_per_pair": float(np.mean(iters)),
+                "pixel_iterations_per_pair": float(np.mean(work)),
+                "step_ms": [round(v, 2) for v in step_ms],
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_tvl1_iter4 (all levels; one launch per inner iteration)",
+                "achieved": bytes_pair / per_pair_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": bytes_pair / per_pair_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_pair": bytes_pair,
+                "what": "64 B x executed pixel-iterations over the whole pair time (pyramid, warps, gradient passes "
+                        "and the host's convergence polling included)"},
+        }
+        if R.world == 1 and not args.no_cpu_baseline:
+            import oracle.tvl1 as ot
+
+            # bounded sample: the same pair at a quarter of the size in each direction
+            a, b = (g[::4, ::4].contiguous().cpu().numpy() for g in gray[:2])
+            tc = time.perf_counter()
+            _f, n_it = ot.calc_gray(a, b)
+            dt = time.perf_counter() - tc
+            line["cpu_baseline"] = {
+                "value": 1.0 / (dt * 16.0), "unit": "pairs/s", "cores": 1, "kind": "port",
+                "sample": f"one pair decimated to {a.shape[1]}x{a.shape[0]} ({dt:.2f} s, {n_it} inner iterations, scalar "
+                          f"C restatement), scaled by the pixel ratio 16 to the full size"}
+        print(json.dumps(line), flush=True)
+    R.finish()
+
+
+def main():
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    if args.workload == "tvl1":
+        bench_tvl1(args)
+    else:
+        bench_solver(args)
 
 
 if __name__ == "__main__":

@@ -176,6 +176,10 @@ SRX_API int srx_collect_garbage(srx_handle* h);
  * DenseOpticalFlow::calc, lib/include/optical_flow.hpp:44). */
 SRX_API int srx_flow_calc_device(srx_handle* h, const float* gray0, const float* gray1, int rows, int cols,
                                  float* flow, long long* executed_iterations);
+/* Work of the handle's last built-in TV-L1 call: pixels x executed inner iterations summed over pyramid
+ * levels and warps (each inner iteration moves 64 bytes per pixel of its level; bench.py prices the flow
+ * stage with it).  No counterpart in the reference. */
+SRX_API int srx_flow_pixel_iterations(srx_handle* h, long long* pixel_iterations);
 
 /* Event trace of the streaming driver (needs traceEvents = 1).  Each event is
  * 5 ints {type, a, b, c, d}: READ{got}, FLOW{i}, SOLVE{idx,start,end,base},

@@ -1113,6 +1113,18 @@ SRX_API int srx_flow_calc_device(srx_handle* h, const float* gray0, const float*
     return SRX_OK;
 }
 
+SRX_API int srx_flow_pixel_iterations(srx_handle* h, long long* pixel_iterations)
+{
+    SRX_NEED(h);
+    if (!pixel_iterations)
+    {
+        set_error("srx_flow_pixel_iterations: NULL argument");
+        return SRX_ERR_INVALID;
+    }
+    *pixel_iterations = h->tvl1.pixel_iterations();
+    return SRX_OK;
+}
+
 SRX_API int srx_collect_garbage(srx_handle* h)
 {
     SRX_NEED(h);

@@ -34,6 +34,9 @@ class Tvl1
     // Same on device-resident grey float images (rows x cols).
     int calc_gray(const float* I0, const float* I1, int rows, int cols, const Tvl1Params& p, float* flow_uv,
                   long long* executed_iters, hipStream_t st);
+    // pixels x executed inner iterations summed over the levels and warps of the last call (the unit of the
+    // flow stage's memory traffic: every inner iteration reads and writes its level's fields once)
+    long long pixel_iterations() const;
     void release();
 
   private:

@@ -638,6 +638,7 @@ struct Tvl1::Impl
     // alike, so this sizes the first batch of launches (results do not depend on it, only the number of
     // launches that find the iteration already converged)
     std::vector<int> last_done;
+    long long pixel_iterations = 0; // sum over (level, warp) of pixels x executed inner iterations, last call
 };
 
 int Tvl1::calc_images(const srx_image& f0, const srx_image& f1, const Tvl1Params& p, float* flow_uv,
@@ -749,6 +750,7 @@ int Tvl1::calc_gray(const float* I0, const float* I1, int rows, int cols, const 
         m.last_done.assign((size_t)nscales * p.warps, kPollStride - 1);
     const float l_t = (float)(p.lambda * p.theta), taut = (float)(p.tau / p.theta), theta = (float)p.theta;
     long long executed = 0;
+    m.pixel_iterations = 0;
     {
         const size_t n = (size_t)m.lv[nscales - 1].rows * m.lv[nscales - 1].cols * sizeof(float);
         SRX_HIP(hipMemsetAsync(m.lv[nscales - 1].u1.get(), 0, n, st));
@@ -825,6 +827,7 @@ int Tvl1::calc_gray(const float* I0, const float* I1, int rows, int cols, const 
                 SRX_HIP(hipMemcpyAsync(pa[0], pa[1], 4 * n * sizeof(float), hipMemcpyDeviceToDevice, st));
             }
             executed += done;
+            m.pixel_iterations += (long long)done * (long long)n;
             predicted = done;
         }
         if (s > 0)
@@ -841,6 +844,11 @@ int Tvl1::calc_gray(const float* I0, const float* I1, int rows, int cols, const 
     if (executed_iters)
         *executed_iters = executed;
     return SRX_OK;
+}
+
+long long Tvl1::pixel_iterations() const
+{
+    return impl_ ? impl_->pixel_iterations : 0;
 }
 
 void Tvl1::release()

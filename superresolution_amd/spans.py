@@ -59,6 +59,19 @@ def exchange_halo(own: Sequence[torch.Tensor], radius: int, rank: Optional[int] 
     return left, right
 
 
+def pair_shard(total_pairs: int, world: int, rank: int) -> Tuple[int, int]:
+    """[first, last) of the frame pairs rank `rank` computes flow for when the flow stage runs on its own.
+
+    Pair t is the motion frame t -> frame t + 1 (opticalFlow->calc(prevFrame, curFrame), lib/src/btv_l1.cpp:522);
+    pairs are independent, so the shards are contiguous, differ by at most one pair and need no exchange beyond
+    the one frame two neighbouring shards both read (rank g reads frames [first, last])."""
+    if world < 1 or not 0 <= rank < world or total_pairs < 0:
+        raise ValueError("pair_shard: need world >= 1, 0 <= rank < world, total_pairs >= 0")
+    base, extra = divmod(total_pairs, world)
+    first = rank * base + min(rank, extra)
+    return first, first + base + (1 if rank < extra else 0)
+
+
 class ListSource:
     """IFrameSource over a list of frames (None = end of stream)."""
 

@@ -1,0 +1,49 @@
+"""bench.py as the driver calls it: `python bench.py --gpus N` starts the N ranks itself.  No GPU here, so the
+ranks run dry-run handles over gloo (SRX_BENCH_REHEARSE=dry): the launcher, the rendezvous, the span plan, the
+halo exchange, the per-rank call sequence and the JSON line are the real ones, the numbers mean nothing."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(argv, **env):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=e, capture_output=True,
+                          text=True, timeout=600)
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_2_starts_two_ranks_and_reports_them():
+    p = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "cfg1", "--iterations", "2"],
+             SRX_BENCH_REHEARSE="dry")
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _json_line(p.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["halo_exchange_ms"] > 0
+    assert d["config"]["span_inclusive"]["outputs_per_gpu"] == 4
+    assert d["config"]["span_inclusive"]["value"] > 0 and d["value"] > 0
+    assert "rehearsal" in d["config"]
+
+
+def test_a_rank_count_other_than_asked_for_is_refused():
+    p = _run(["--gpus", "1", "--workload", "cfg1"], SRX_BENCH_REHEARSE="dry", WORLD_SIZE="2", RANK="0")
+    assert p.returncode != 0
+    assert "refusing" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_a_failing_rank_fails_the_launcher():
+    # the tvl1 workload cannot run on dry-run handles: the ranks exit non-zero and so must the parent
+    p = _run(["--gpus", "2", "--workload", "tvl1"], SRX_BENCH_REHEARSE="dry")
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
