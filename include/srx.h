@@ -279,6 +279,21 @@ SRX_API int srx_quality_psnr(const srx_image* a, const srx_image* b, double* psn
 SRX_API int srx_quality_mssim(const srx_image* a, const srx_image* b, double* per_channel, double* mssim,
                               void* stream);
 
+/* srx_quality_psnr for callers that cannot allocate device memory: code that sets
+ * up or replays a captured HIP graph, tight serving loops, harnesses that forbid
+ * hipMalloc.  It has no counterpart in the reference.  Same arguments and the same
+ * result, bit for bit, as srx_quality_psnr, with these limits:
+ *  - both images in device memory (SRX_MEM_DEVICE) on the current device;
+ *  - at most 65536 row segments of 4096 bytes (rows * ceil(cols * channels /
+ *    4096)), e.g. up to 65536 rows of 4096 bytes or 3840x2160 RGB (6480);
+ *    larger pairs are refused with SRX_ERR_INVALID and a message.
+ * The partial sums live in an array of 520 KiB that the library holds in every
+ * GPU's memory from load to exit; the call makes no hipMalloc / hipFree and uses no
+ * allocating library routine (two kernel launches, an 8-byte copy to the host, a
+ * stream synchronise).  All calls on one GPU share that array: calls that overlap
+ * in time on one GPU (other streams, other threads) race; order them. */
+SRX_API int srx_quality_psnr_noalloc(const srx_image* a, const srx_image* b, double* psnr, void* stream);
+
 /* BTV_L1_Base::run, lib/src/btv_l1.cpp:357-457, on device-resident inputs
  * with the handle's parameters.  y_host / rel_host: host arrays of K device
  * pointers (float LR frames rows x cols x ch; relative motions rows x cols x

@@ -86,6 +86,7 @@ SIGNATURES = {
     "srx_run": (C.c_int, [_vp, _vpp, _vpp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "srx_process_device": (C.c_int, [_vp, _vpp, _vpp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "srx_quality_psnr": (C.c_int, [C.POINTER(SrxImage), C.POINTER(SrxImage), C.POINTER(C.c_double), _vp]),
+    "srx_quality_psnr_noalloc": (C.c_int, [C.POINTER(SrxImage), C.POINTER(SrxImage), C.POINTER(C.c_double), _vp]),
     "srx_quality_mssim": (C.c_int, [C.POINTER(SrxImage), C.POINTER(SrxImage), C.POINTER(C.c_double),
                                     C.POINTER(C.c_double), _vp]),
     "srx_set_kernel_path": (C.c_int, [C.c_int]),

@@ -1515,6 +1515,16 @@ SRX_API int srx_quality_psnr(const srx_image* a, const srx_image* b, double* psn
     return quality_psnr(*a, *b, psnr, (hipStream_t)stream);
 }
 
+SRX_API int srx_quality_psnr_noalloc(const srx_image* a, const srx_image* b, double* psnr, void* stream)
+{
+    if (!a || !b || !psnr)
+    {
+        set_error("srx_quality_psnr_noalloc: NULL argument");
+        return SRX_ERR_INVALID;
+    }
+    return quality_psnr_noalloc(*a, *b, psnr, (hipStream_t)stream);
+}
+
 SRX_API int srx_quality_mssim(const srx_image* a, const srx_image* b, double* per_channel, double* mssim, void* stream)
 {
     if (!a || !b || (!per_channel && !mssim))

@@ -92,6 +92,7 @@ int validate_params(const Params& p);
 // Quality metrics (srx_quality.hip): cv::PSNR and the MSSIM of samples/quality_test/main.cpp:140-199.
 // Images may live in host or device memory; the calls return when the result is on the host.
 int quality_psnr(const srx_image& a, const srx_image& b, double* psnr, hipStream_t st);
+int quality_psnr_noalloc(const srx_image& a, const srx_image& b, double* psnr, hipStream_t st);
 int quality_mssim(const srx_image& a, const srx_image& b, double* per_channel, double* mssim, hipStream_t st);
 
 // Host-built cv::resize(INTER_CUBIC) tap tables

@@ -12,6 +12,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <mutex>
 #include <vector>
 
 namespace srx
@@ -65,6 +66,61 @@ __global__ __launch_bounds__(256) void k_sqdiff_8u(const uint8_t* __restrict__ a
     __syncthreads();
     if (threadIdx.x == 0)
         partial[blockIdx.x] = (unsigned long long)wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// Partial sums of the variant of quality_psnr that allocates nothing: kNoAllocMaxBlocks partials, then one
+// 256-byte slot for the total.  Every GPU the library runs on holds its own copy of this array (520 KiB) at
+// its own address until the process ends; host code reaches it only through the per-device address taken with
+// hipGetSymbolAddress (the array's name is not a device address on the host side).  The array keeps the
+// contents of the last call; a call overwrites every element it reads.
+constexpr size_t kNoAllocMaxBlocks = 65536;
+constexpr size_t kNoAllocTotalSlot = kNoAllocMaxBlocks;
+static __device__ __align__(256) unsigned long long scratch[kNoAllocMaxBlocks + 32];
+
+constexpr int kMaxScratchDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned long long* g_scratch_ptr[kMaxScratchDevices] = {};
+
+// Address of `scratch` on the current device, looked up once per device.
+int scratch_of_current_device(unsigned long long** out)
+{
+    int dev = -1;
+    SRX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxScratchDevices)
+    {
+        set_error("psnr (no allocation): device index out of range");
+        return SRX_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev])
+    {
+        void* p = nullptr;
+        SRX_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p)
+        {
+            set_error("psnr (no allocation): the scratch array has no address on this device");
+            return SRX_ERR_DEVICE;
+        }
+        g_scratch_ptr[dev] = static_cast<unsigned long long*>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return SRX_OK;
+}
+
+// Adds `n` partials into *total (one block; integer sums, so the order is free).
+__global__ __launch_bounds__(256) void k_sum_partials(const unsigned long long* __restrict__ partial, unsigned n,
+                                                       unsigned long long* __restrict__ total)
+{
+    __shared__ unsigned long long wsum[4];
+    unsigned long long s = 0;
+    for (unsigned i = threadIdx.x; i < n; i += 256)
+        s += partial[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0)
+        wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 struct Gauss11
@@ -241,6 +297,50 @@ int quality_psnr(const srx_image& a, const srx_image& b, double* psnr, hipStream
     for (unsigned long long v : h)
         s += v;
     // cv::PSNR: sqrt(norm(a, b, NORM_L2SQR) / (total * channels)); 20 log10(255 / (diff + DBL_EPSILON))
+    const double diff = std::sqrt((double)s / ((double)a.rows * a.cols * a.channels));
+    *psnr = 20.0 * std::log10(255.0 / (diff + DBL_EPSILON));
+    return SRX_OK;
+}
+
+// quality_psnr for callers that cannot allocate (code under stream capture set-up, tight serving loops, harnesses
+// that forbid hipMalloc): device images only, partial sums in the per-device static array, the total formed on
+// the device.  Runtime calls: two kernel launches, one 8-byte copy to the host, one stream synchronise.
+// Calls that overlap on one GPU share the array and race.
+int quality_psnr_noalloc(const srx_image& a, const srx_image& b, double* psnr, hipStream_t st)
+{
+    if (int rc = check_pair(a, b, "psnr (no allocation)"))
+        return rc;
+    if (a.depth != SRX_8U)
+    {
+        set_error("psnr (no allocation): 8-bit images only (cv::PSNR asserts CV_8U)");
+        return SRX_ERR_INVALID;
+    }
+    if (a.mem != SRX_MEM_DEVICE || b.mem != SRX_MEM_DEVICE)
+    {
+        set_error("psnr (no allocation): both images must be in device memory (a host image needs a staging buffer)");
+        return SRX_ERR_INVALID;
+    }
+    const int rowbytes = a.cols * a.channels;
+    const int segs = (rowbytes + kSegBytes - 1) / kSegBytes;
+    const size_t blocks = (size_t)segs * a.rows;
+    if (blocks > kNoAllocMaxBlocks)
+    {
+        set_error("psnr (no allocation): " + std::to_string(blocks) + " row segments of 4096 bytes, the limit is " +
+                  std::to_string(kNoAllocMaxBlocks) + " (use srx_quality_psnr)");
+        return SRX_ERR_INVALID;
+    }
+    unsigned long long* part = nullptr;
+    if (int rc = scratch_of_current_device(&part))
+        return rc;
+    const size_t rb = (size_t)rowbytes;
+    hipLaunchKernelGGL(k_sqdiff_8u, dim3((unsigned)blocks), dim3(256), 0, st, (const uint8_t*)a.data,
+                       a.step ? a.step : rb, (const uint8_t*)b.data, b.step ? b.step : rb, rowbytes, segs, part);
+    SRX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, part, (unsigned)blocks, part + kNoAllocTotalSlot);
+    SRX_HIP(hipGetLastError());
+    unsigned long long s = 0;
+    SRX_HIP(hipMemcpyAsync(&s, part + kNoAllocTotalSlot, sizeof(s), hipMemcpyDeviceToHost, st));
+    SRX_HIP(hipStreamSynchronize(st));
     const double diff = std::sqrt((double)s / ((double)a.rows * a.cols * a.channels));
     *psnr = 20.0 * std::log10(255.0 / (diff + DBL_EPSILON));
     return SRX_OK;

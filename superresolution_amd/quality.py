@@ -56,12 +56,14 @@ def _stream(a):
     return None
 
 
-def PSNR(a, b) -> float:
-    """cv::PSNR of two 8-bit images (samples/quality_test/main.cpp:320,323)."""
+def PSNR(a, b, allocate: bool = True) -> float:
+    """cv::PSNR of two 8-bit images (samples/quality_test/main.cpp:320,323).  allocate=False takes the entry point
+    that makes no device allocation (device images of bounded size only, see srx_quality_psnr_noalloc)."""
     keep: list = []
     ha, hb = _header(a, keep), _header(b, keep)
     out = C.c_double()
-    L.check(L.lib().srx_quality_psnr(C.byref(ha), C.byref(hb), C.byref(out), _stream(a)))
+    fn = L.lib().srx_quality_psnr if allocate else L.lib().srx_quality_psnr_noalloc
+    L.check(fn(C.byref(ha), C.byref(hb), C.byref(out), _stream(a)))
     return out.value
 
 
