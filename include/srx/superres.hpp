@@ -20,6 +20,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace srx
@@ -154,6 +155,9 @@ class DenseOpticalFlow
     // flow1: rows x cols x 2 float (dx, dy interleaved); flow2 given: planar u and v
     virtual void calc(const Mat& frame0, const Mat& frame1, Mat& flow1, Mat* flow2 = nullptr) = 0;
     virtual void collectGarbage() {}
+    // true: the super-resolution object asks for the two-output form calc(f0, f1, u, &v), as the reference's
+    // GPU class does (lib/src/btv_l1_gpu.cpp:243,460); false: flow1 only, as lib/src/btv_l1.cpp:315,522
+    virtual bool planar() const { return false; }
 };
 using DenseOpticalFlowExt = DenseOpticalFlow; // upstream spelling
 
@@ -195,7 +199,8 @@ inline Ptr<DenseOpticalFlow> createOptFlow_Farneback()
 }
 
 // The part of cv::Algorithm that the reference's programs use on a Ptr<SuperResolution>
-// (samples/quality_test/main.cpp:261-267): parameters by name.
+// (samples/quality_test/main.cpp:261-267): parameters by name, and creation by registered name
+// (Algorithm::create<SuperResolution>("SuperResolution.BTV_L1") once initModule_superres() has run).
 class Algorithm
 {
   public:
@@ -205,6 +210,212 @@ class Algorithm
     virtual void set(const std::string& name, const Ptr<DenseOpticalFlow>& flow) = 0;
     virtual int getInt(const std::string& name) const = 0;
     virtual double getDouble(const std::string& name) const = 0;
+    virtual std::string name() const { return std::string(); }
+
+    typedef Ptr<Algorithm> (*Constructor)(int device);
+    // registered names, in registration order (cv::Algorithm::getList)
+    static void getList(std::vector<std::string>& names)
+    {
+        names.clear();
+        for (const auto& e : registry())
+            names.push_back(e.first);
+    }
+    // cv::Algorithm::create<T>(name): an empty Ptr for a name that is not registered or is of another type
+    template <typename T> static Ptr<T> create(const std::string& name)
+    {
+        for (const auto& e : registry())
+            if (e.first == name)
+                return std::dynamic_pointer_cast<T>(e.second(defaultDevice()));
+        return Ptr<T>();
+    }
+    // objects made by create() live on this GPU (-1: dry-run objects, host bookkeeping only)
+    static int& defaultDevice()
+    {
+        static int device = 0;
+        return device;
+    }
+    static bool registerAlgorithm(const std::string& name, Constructor make)
+    {
+        for (const auto& e : registry())
+            if (e.first == name)
+                return true;
+        registry().emplace_back(name, make);
+        return true;
+    }
+
+  private:
+    static std::vector<std::pair<std::string, Constructor>>& registry()
+    {
+        static std::vector<std::pair<std::string, Constructor>> r;
+        return r;
+    }
+};
+
+// lib/include/super_resolution.hpp:46-88.  The parameters are public members, as in the reference; they are
+// handed to the library at every process() call, where out-of-range values (which the reference only
+// debug-asserts, lib/src/btv_l1.cpp:359-365) raise srx::Exception.
+class BTV_L1_Base
+{
+  public:
+    // device: GPU ordinal; -1 creates a dry-run object (host bookkeeping only)
+    explicit BTV_L1_Base(int device = 0)
+    {
+        check(srx_create_btvl1(device, &h_));
+        opticalFlow = std::make_shared<Farneback>(); // opticalFlow = new Farneback, lib/src/btv_l1.cpp:287
+    }
+    virtual ~BTV_L1_Base() { srx_destroy(h_); }
+    BTV_L1_Base(const BTV_L1_Base&) = delete;
+    BTV_L1_Base& operator=(const BTV_L1_Base&) = delete;
+
+    // lib/src/btv_l1.cpp:297-355; dst is allocated (host) when empty.  Without forwardMotions the motions come
+    // from opticalFlow (lib/src/btv_l1.cpp:297-321).
+    void process(const std::vector<Mat>& src, Mat& dst, int baseIdx = 0) { process_impl(src, dst, nullptr, baseIdx); }
+    void process(const std::vector<Mat>& src, Mat& dst, const std::vector<Mat>& forwardMotions, int baseIdx = 0)
+    {
+        if (forwardMotions.size() + 1 != src.size())
+            throw Exception(SRX_ERR_INVALID, "forwardMotions must have src.size() - 1 entries");
+        process_impl(src, dst, &forwardMotions, baseIdx);
+    }
+
+    // lib/include/super_resolution.hpp:54-62, defaults of lib/src/btv_l1.cpp:277-288
+    int scale = 4;
+    int iterations = 180;
+    double tau = 1.3;
+    double lambda = 0.03;
+    double alpha = 0.7;
+    int btvKernelSize = 7;
+    int blurKernelSize = 5;
+    double blurSigma = 0.0;
+    Ptr<DenseOpticalFlow> opticalFlow;
+
+    srx_handle* handle() const { return h_; }
+
+  protected:
+    // members -> library.  Values the library already holds are not sent again.
+    void pushParams()
+    {
+        pushInt("scale", scale);
+        pushInt("iterations", iterations);
+        pushDouble("tau", tau);
+        pushDouble("lambda", lambda);
+        pushDouble("alpha", alpha);
+        pushInt("btvKernelSize", btvKernelSize);
+        pushInt("blurKernelSize", blurKernelSize);
+        pushDouble("blurSigma", blurSigma);
+        if (opticalFlow != bound_flow_ || flowChanged())
+            bindFlow();
+    }
+    void pushInt(const char* name, int v)
+    {
+        int cur = 0;
+        check(srx_get_int(h_, name, &cur));
+        if (cur != v)
+            check(srx_set_int(h_, name, v));
+    }
+    void pushDouble(const char* name, double v)
+    {
+        double cur = 0;
+        check(srx_get_double(h_, name, &cur));
+        if (cur != v)
+            check(srx_set_double(h_, name, v));
+    }
+    // the parameters of a built-in Farneback object are public members too: resend when they were edited
+    bool flowChanged() const
+    {
+        const Farneback* fb = dynamic_cast<const Farneback*>(opticalFlow.get());
+        return fb && (fb->pyrScale != fb_sent_.pyrScale || fb->numLevels != fb_sent_.numLevels ||
+                      fb->winSize != fb_sent_.winSize || fb->numIters != fb_sent_.numIters ||
+                      fb->polyN != fb_sent_.polyN || fb->polySigma != fb_sent_.polySigma ||
+                      fb->flags != fb_sent_.flags);
+    }
+    void bindFlow()
+    {
+        DenseOpticalFlow* f = opticalFlow.get();
+        if (!f)
+            check(srx_set_flow_builtin(h_, SRX_FLOW_NONE));
+        else if (dynamic_cast<DualTVL1*>(f))
+            check(srx_set_flow_builtin(h_, SRX_FLOW_TVL1));
+        else if (const Farneback* fb = dynamic_cast<Farneback*>(f))
+        {
+            check(srx_set_flow_builtin(h_, SRX_FLOW_FARNEBACK));
+            check(srx_flow_set_double(h_, "pyrScale", fb->pyrScale));
+            check(srx_flow_set_int(h_, "numLevels", fb->numLevels));
+            check(srx_flow_set_int(h_, "winSize", fb->winSize));
+            check(srx_flow_set_int(h_, "numIters", fb->numIters));
+            check(srx_flow_set_int(h_, "polyN", fb->polyN));
+            check(srx_flow_set_double(h_, "polySigma", fb->polySigma));
+            check(srx_flow_set_int(h_, "flags", fb->flags));
+            fb_sent_.pyrScale = fb->pyrScale, fb_sent_.numLevels = fb->numLevels, fb_sent_.winSize = fb->winSize;
+            fb_sent_.numIters = fb->numIters, fb_sent_.polyN = fb->polyN, fb_sent_.polySigma = fb->polySigma;
+            fb_sent_.flags = fb->flags;
+        }
+        else if (f->planar())
+            check(srx_set_flow_callback2(h_, &BTV_L1_Base::flow2_thunk, this));
+        else
+            check(srx_set_flow_callback(h_, &BTV_L1_Base::flow_thunk, this));
+        bound_flow_ = opticalFlow;
+    }
+
+    srx_handle* h_ = nullptr;
+
+  private:
+    // The results stay alive in flow_out_ / flow_out2_ until the plug-in is called again, which is as long as
+    // the library may read them.
+    static int flow_thunk(void* user, const srx_image* f0, const srx_image* f1, srx_image* flow)
+    {
+        BTV_L1_Base* self = static_cast<BTV_L1_Base*>(user);
+        try
+        {
+            self->bound_flow_->calc(Mat(*f0), Mat(*f1), self->flow_out_, nullptr);
+        }
+        catch (...)
+        {
+            return 1;
+        }
+        if (self->flow_out_.empty())
+            return 1;
+        *flow = self->flow_out_.view();
+        return 0;
+    }
+    // calc(frame0, frame1, flow1, flow2): planar u and v (lib/src/optical_flow.cpp:71-81)
+    static int flow2_thunk(void* user, const srx_image* f0, const srx_image* f1, srx_image* u, srx_image* v)
+    {
+        BTV_L1_Base* self = static_cast<BTV_L1_Base*>(user);
+        try
+        {
+            self->bound_flow_->calc(Mat(*f0), Mat(*f1), self->flow_out_, &self->flow_out2_);
+        }
+        catch (...)
+        {
+            return 1;
+        }
+        if (self->flow_out_.empty() || self->flow_out2_.empty())
+            return 1;
+        *u = self->flow_out_.view();
+        *v = self->flow_out2_.view();
+        return 0;
+    }
+    void process_impl(const std::vector<Mat>& src, Mat& dst, const std::vector<Mat>* motions, int baseIdx)
+    {
+        if (src.empty())
+            throw Exception(SRX_ERR_INVALID, "process: no frames");
+        pushParams();
+        std::vector<srx_image> f, m;
+        for (const Mat& s : src)
+            f.push_back(s.view());
+        if (motions)
+            for (const Mat& s : *motions)
+                m.push_back(s.view());
+        if (dst.empty())
+            dst.create(src[0].rows() * scale - 2 * btvKernelSize, src[0].cols() * scale - 2 * btvKernelSize,
+                       src[0].channels(), src[0].depth());
+        srx_image out = dst.view();
+        check(srx_process(h_, f.data(), (int)f.size(), motions ? m.data() : nullptr, baseIdx, &out));
+    }
+
+    Ptr<DenseOpticalFlow> bound_flow_; // what the library's call-back reaches
+    Farneback fb_sent_;
+    Mat flow_out_, flow_out2_;
 };
 
 // lib/include/super_resolution.hpp:146-163
@@ -216,23 +427,36 @@ class SuperResolution : public Algorithm, public IFrameSource
     virtual void setOpticalFlow(const Ptr<DenseOpticalFlow>& flow) = 0;
 };
 
-// SuperResolution.BTV_L1 (lib/include/super_resolution.hpp:165-195)
-class BTV_L1 : public SuperResolution
+// SuperResolution.BTV_L1 (lib/include/super_resolution.hpp:165-195).  The reference derives privately from
+// BTV_L1_Base and reaches the solver's parameters by name only; here the process() overloads stay reachable
+// as well (programs of this repository use them on the streaming object).
+class BTV_L1 : public SuperResolution, private BTV_L1_Base
 {
   public:
-    // device: GPU ordinal; -1 creates a dry-run object (host bookkeeping only)
-    explicit BTV_L1(int device = 0)
-    {
-        check(srx_create_btvl1(device, &h_));
-        flow_ = std::make_shared<Farneback>(); // opticalFlow = new Farneback, lib/src/btv_l1.cpp:287 (the library's default)
-    }
-    ~BTV_L1() override { srx_destroy(h_); }
+    explicit BTV_L1(int device = 0) : BTV_L1_Base(device) {}
     BTV_L1(const BTV_L1&) = delete;
     BTV_L1& operator=(const BTV_L1&) = delete;
 
-    // ---- Algorithm::set / get with the names of lib/src/super_resolution.cpp:83-93
-    void set(const std::string& name, int v) override { check(srx_set_int(h_, name.c_str(), v)); }
-    void set(const std::string& name, double v) override { check(srx_set_double(h_, name.c_str(), v)); }
+    int temporalAreaRadius = 4; // lib/include/super_resolution.hpp:172; read when the stream (re)starts
+
+    std::string name() const override { return "SuperResolution.BTV_L1"; }
+    using BTV_L1_Base::handle;
+    using BTV_L1_Base::process;
+
+    // ---- Algorithm::set / get with the names of lib/src/super_resolution.cpp:83-93.  A value the library
+    // refuses raises srx::Exception and leaves the parameter as it was.
+    void set(const std::string& name, int v) override
+    {
+        check(srx_set_int(h_, name.c_str(), v));
+        if (int* m = intMember(name))
+            *m = v;
+    }
+    void set(const std::string& name, double v) override
+    {
+        check(srx_set_double(h_, name.c_str(), v));
+        if (double* m = doubleMember(name))
+            *m = v;
+    }
     void set(const std::string& name, const Ptr<DenseOpticalFlow>& flow) override
     {
         if (name != "opticalFlow")
@@ -241,12 +465,16 @@ class BTV_L1 : public SuperResolution
     }
     int getInt(const std::string& name) const override
     {
+        if (const int* m = const_cast<BTV_L1*>(this)->intMember(name))
+            return *m;
         int v = 0;
         check(srx_get_int(h_, name.c_str(), &v));
         return v;
     }
     double getDouble(const std::string& name) const override
     {
+        if (const double* m = const_cast<BTV_L1*>(this)->doubleMember(name))
+            return *m;
         double v = 0;
         check(srx_get_double(h_, name.c_str(), &v));
         return v;
@@ -274,28 +502,13 @@ class BTV_L1 : public SuperResolution
     int getTemporalAreaRadius() const { return getInt("temporalAreaRadius"); }
     void setTemporalAreaRadius(int v) { set("temporalAreaRadius", v); }
 
+    // A refused flow object (e.g. Farneback flags the library does not build) raises srx::Exception.
     void setOpticalFlow(const Ptr<DenseOpticalFlow>& flow) override
     {
-        flow_ = flow;
-        if (!flow)
-            check(srx_set_flow_builtin(h_, SRX_FLOW_NONE));
-        else if (dynamic_cast<DualTVL1*>(flow.get()))
-            check(srx_set_flow_builtin(h_, SRX_FLOW_TVL1));
-        else if (const Farneback* fb = dynamic_cast<Farneback*>(flow.get()))
-        {
-            check(srx_set_flow_builtin(h_, SRX_FLOW_FARNEBACK));
-            setFlowParam("pyrScale", fb->pyrScale);
-            setFlowParam("numLevels", fb->numLevels);
-            setFlowParam("winSize", fb->winSize);
-            setFlowParam("numIters", fb->numIters);
-            setFlowParam("polyN", fb->polyN);
-            setFlowParam("polySigma", fb->polySigma);
-            setFlowParam("flags", fb->flags);
-        }
-        else
-            check(srx_set_flow_callback(h_, &BTV_L1::flow_thunk, this));
+        opticalFlow = flow;
+        bindFlow();
     }
-    Ptr<DenseOpticalFlow> getOpticalFlow() const { return flow_; }
+    Ptr<DenseOpticalFlow> getOpticalFlow() const { return opticalFlow; }
     void setFlowParam(const std::string& name, int v) { check(srx_flow_set_int(h_, name.c_str(), v)); }
     void setFlowParam(const std::string& name, double v) { check(srx_flow_set_double(h_, name.c_str(), v)); }
 
@@ -317,6 +530,8 @@ class BTV_L1 : public SuperResolution
     // lib/src/btv_l1.cpp:504-505); clone() to keep it.
     Mat nextFrame() override
     {
+        pushParams();
+        pushInt("temporalAreaRadius", temporalAreaRadius);
         srx_image out{};
         check(srx_next_frame(h_, &out));
         return out.rows == 0 ? Mat() : Mat(out);
@@ -326,17 +541,10 @@ class BTV_L1 : public SuperResolution
     void setOutputOnDevice(bool on) { set("outputMemory", on ? SRX_MEM_DEVICE : SRX_MEM_HOST); }
     void setReadAhead(bool on) { set("readAhead", on ? 1 : 0); } // next frame's flow beside the current solve
 
-    // ---- BTV_L1_Base::process (lib/src/btv_l1.cpp:297-355); dst is allocated (host) when empty
-    void process(const std::vector<Mat>& src, Mat& dst, int baseIdx = 0) { process_impl(src, dst, nullptr, baseIdx); }
-    void process(const std::vector<Mat>& src, Mat& dst, const std::vector<Mat>& forwardMotions, int baseIdx = 0)
-    {
-        if (forwardMotions.size() + 1 != src.size())
-            throw Exception(SRX_ERR_INVALID, "forwardMotions must have src.size() - 1 entries");
-        process_impl(src, dst, &forwardMotions, baseIdx);
-    }
     // DenseOpticalFlow::calc through this object's flow (lib/include/optical_flow.hpp:44)
     void calcFlow(const Mat& frame0, const Mat& frame1, Mat& flow1, Mat* flow2 = nullptr)
     {
+        pushParams();
         if (flow2)
         {
             flow1.create(frame0.rows(), frame0.cols(), 1, SRX_32F);
@@ -353,13 +561,22 @@ class BTV_L1 : public SuperResolution
     }
     void collectGarbage()
     {
-        if (flow_)
-            flow_->collectGarbage();
+        if (opticalFlow)
+            opticalFlow->collectGarbage();
         check(srx_collect_garbage(h_));
     }
-    srx_handle* handle() const { return h_; }
 
   private:
+    int* intMember(const std::string& n)
+    {
+        return n == "scale" ? &scale : n == "iterations" ? &iterations : n == "btvKernelSize" ? &btvKernelSize
+             : n == "blurKernelSize" ? &blurKernelSize : n == "temporalAreaRadius" ? &temporalAreaRadius : nullptr;
+    }
+    double* doubleMember(const std::string& n)
+    {
+        return n == "tau" ? &tau : n == "lambda" ? &lambda : n == "alpha" ? &alpha : n == "blurSigma" ? &blurSigma
+                                                                                                        : nullptr;
+    }
     static int next_thunk(void* user, srx_image* out)
     {
         BTV_L1* self = static_cast<BTV_L1*>(user);
@@ -389,45 +606,12 @@ class BTV_L1 : public SuperResolution
         else if (self->ext_source_)
             self->ext_source_->reset();
     }
-    static int flow_thunk(void* user, const srx_image* f0, const srx_image* f1, srx_image* flow)
-    {
-        BTV_L1* self = static_cast<BTV_L1*>(user);
-        try
-        {
-            self->flow_->calc(Mat(*f0), Mat(*f1), self->flow_out_, nullptr);
-        }
-        catch (...)
-        {
-            return 1;
-        }
-        if (self->flow_out_.empty())
-            return 1;
-        *flow = self->flow_out_.view();
-        return 0;
-    }
-    void process_impl(const std::vector<Mat>& src, Mat& dst, const std::vector<Mat>* motions, int baseIdx)
-    {
-        if (src.empty())
-            throw Exception(SRX_ERR_INVALID, "process: no frames");
-        std::vector<srx_image> f, m;
-        for (const Mat& s : src)
-            f.push_back(s.view());
-        if (motions)
-            for (const Mat& s : *motions)
-                m.push_back(s.view());
-        const int s = getScale(), B = getKernelSize();
-        if (dst.empty())
-            dst.create(src[0].rows() * s - 2 * B, src[0].cols() * s - 2 * B, src[0].channels(), src[0].depth());
-        srx_image out = dst.view();
-        check(srx_process(h_, f.data(), (int)f.size(), motions ? m.data() : nullptr, baseIdx, &out));
-    }
 
-    srx_handle* h_ = nullptr;
     Ptr<IFrameSource> source_;
     Ptr<FrameSource> ext_source_;
-    Ptr<DenseOpticalFlow> flow_;
-    Mat cur_, flow_out_;
+    Mat cur_;
 };
+using BTV_L1_GPU = BTV_L1; // the reference's second class of the same interface (lib/include/super_resolution.hpp:197)
 
 // upstream factory spelling of `new BTV_L1` (samples/video/main.cpp:106)
 inline Ptr<BTV_L1> createSuperResolution_BTVL1(int device = 0)
@@ -435,10 +619,22 @@ inline Ptr<BTV_L1> createSuperResolution_BTVL1(int device = 0)
     return std::make_shared<BTV_L1>(device);
 }
 
-// initModule_superres (lib/src/super_resolution.cpp:109-123): nothing to register here
+// initModule_superres (lib/src/super_resolution.cpp:109-123): registers the algorithms this library builds under
+// the reference's names, so that Algorithm::create<SuperResolution>("SuperResolution.BTV_L1") works as it does
+// after the reference's call.  True when every name is in the list afterwards.  The flow classes the reference
+// registers beside Farneback (Simple, Brox_GPU, PyrLK_GPU) are not built and not registered.
 inline bool initModule_superres()
 {
-    return true;
+    Algorithm::registerAlgorithm("SuperResolution.BTV_L1",
+                                 [](int device) -> Ptr<Algorithm> { return std::make_shared<BTV_L1>(device); });
+    Algorithm::registerAlgorithm("SuperResolution.BTV_L1_GPU",
+                                 [](int device) -> Ptr<Algorithm> { return std::make_shared<BTV_L1>(device); });
+    std::vector<std::string> names;
+    Algorithm::getList(names);
+    bool btv = false, btv_gpu = false;
+    for (const std::string& n : names)
+        btv |= n == "SuperResolution.BTV_L1", btv_gpu |= n == "SuperResolution.BTV_L1_GPU";
+    return btv && btv_gpu;
 }
 
 } // namespace srx

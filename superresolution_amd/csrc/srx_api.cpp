@@ -912,11 +912,8 @@ SRX_API int srx_process(srx_handle* h, const srx_image* frames, int n, const srx
                         srx_image* out)
 {
     SRX_NEED(h);
-    if (h->dry)
-    {
-        set_error("srx_process needs a GPU handle");
-        return SRX_ERR_STATE;
-    }
+    // a dry-run handle checks the arguments and calls the flow plug-in as often as a real one, and computes nothing
+    const bool dry = h->dry;
     if (!frames || !out || n < 1 || n > kMaxWindow || base_idx < 0 || base_idx >= n)
     {
         set_error("srx_process: bad frame list or base index");
@@ -952,7 +949,7 @@ SRX_API int srx_process(srx_handle* h, const srx_image* frames, int n, const srx
     }
     const float* y[kMaxWindow];
     const float* m[kMaxWindow];
-    for (int i = 0; i < n; ++i)
+    for (int i = 0; i < n && !dry; ++i)
     {
         if (int rc = h->batch_frames[i].reserve(px * ch * sizeof(float)))
             return rc;
@@ -982,12 +979,16 @@ SRX_API int srx_process(srx_handle* h, const srx_image* frames, int n, const srx
                 set_error("srx_process: motions must be rows x cols x 2 float");
                 return SRX_ERR_INVALID;
             }
+            if (dry)
+                continue;
             if ((rc = h->batch_motions[i].reserve(px * 2 * sizeof(float))))
                 return rc;
             if ((rc = copy_to_device(motions[i], h->batch_motions[i].get(), h->stream)))
                 return rc;
             m[i] = h->batch_motions[i].as<float>();
         }
+        if (dry)
+            return SRX_OK;
         rc = h->solver.process(y, m, n, base_idx, rows, cols, ch, h->p, nullptr, nullptr, h->stream);
     }
     else
@@ -995,6 +996,12 @@ SRX_API int srx_process(srx_handle* h, const srx_image* frames, int n, const srx
         // flow frame i -> base for every i != base, zero for the base (lib/src/btv_l1.cpp:311-321)
         for (int i = 0; i < n; ++i)
         {
+            if (dry)
+            {
+                if (i != base_idx && (rc = h->calc_flow(frames[i], frames[base_idx], nullptr)))
+                    return rc;
+                continue;
+            }
             if ((rc = h->batch_motions[i].reserve(px * 2 * sizeof(float))))
                 return rc;
             if (i == base_idx)
@@ -1003,6 +1010,8 @@ SRX_API int srx_process(srx_handle* h, const srx_image* frames, int n, const srx
                 return rc;
             m[i] = h->batch_motions[i].as<float>();
         }
+        if (dry)
+            return SRX_OK;
         rc = h->solver.run(y, m, n, base_idx, rows, cols, ch, h->p, nullptr, nullptr, h->stream);
     }
     if (rc)

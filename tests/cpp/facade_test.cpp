@@ -46,9 +46,81 @@ struct ZeroFlow : DenseOpticalFlow
     }
 };
 
+// the two-output form: planar u and v
+struct PlanarZeroFlow : DenseOpticalFlow
+{
+    int calls = 0;
+    bool planar() const override { return true; }
+    void calc(const Mat& f0, const Mat&, Mat& u, Mat* v) override
+    {
+        REQUIRE(v != nullptr);
+        u.create(f0.rows(), f0.cols(), 1, SRX_32F);
+        v->create(f0.rows(), f0.cols(), 1, SRX_32F);
+        ++calls;
+    }
+};
+
 int main()
 {
+    // creation by registered name, as after the reference's initModule_superres()
+    // (lib/src/super_resolution.cpp:83-123)
+    Algorithm::defaultDevice() = -1;
+    REQUIRE(!Algorithm::create<SuperResolution>("SuperResolution.BTV_L1")); // not registered yet
     REQUIRE(initModule_superres());
+    REQUIRE(initModule_superres()); // a second call registers nothing twice
+    {
+        std::vector<std::string> names;
+        Algorithm::getList(names);
+        REQUIRE(names.size() == 2 && names[0] == "SuperResolution.BTV_L1" && names[1] == "SuperResolution.BTV_L1_GPU");
+        Ptr<SuperResolution> made = Algorithm::create<SuperResolution>("SuperResolution.BTV_L1");
+        REQUIRE(made && made->name() == "SuperResolution.BTV_L1");
+        REQUIRE(made->getInt("scale") == 4 && made->getInt("temporalAreaRadius") == 4);
+        made->set("scale", 2);
+        made->set("temporalAreaRadius", 1);
+        auto planar = std::make_shared<PlanarZeroFlow>();
+        made->set("opticalFlow", Ptr<DenseOpticalFlow>(planar));
+        made->setFrameSource(std::make_shared<CountingSource>(5));
+        int outs = 0;
+        while (!made->nextFrame().empty())
+            ++outs;
+        REQUIRE(outs == 5 && planar->calls == 4);
+        REQUIRE(!Algorithm::create<SuperResolution>("SuperResolution.Unknown"));
+        REQUIRE(!Algorithm::create<DenseOpticalFlow>("SuperResolution.BTV_L1")); // another type: empty, as cv::Algorithm
+    }
+
+    // BTV_L1_Base on its own (lib/include/super_resolution.hpp:46-62): public members, both process overloads
+    {
+        BTV_L1_Base base(-1);
+        REQUIRE(base.scale == 4 && base.iterations == 180 && base.tau == 1.3 && base.lambda == 0.03);
+        REQUIRE(base.alpha == 0.7 && base.btvKernelSize == 7 && base.blurKernelSize == 5 && base.blurSigma == 0.0);
+        REQUIRE(dynamic_cast<Farneback*>(base.opticalFlow.get()) != nullptr);
+        base.scale = 2;
+        base.btvKernelSize = 5;
+        auto zf = std::make_shared<ZeroFlow>();
+        base.opticalFlow = zf;
+        std::vector<Mat> src(3, Mat(12, 16, 1, SRX_8U));
+        Mat dst;
+        base.process(src, dst, 1); // motions from opticalFlow: one call per frame other than the base
+        REQUIRE(zf->calls == 2);
+        REQUIRE(dst.rows() == 12 * 2 - 10 && dst.cols() == 16 * 2 - 10 && dst.channels() == 1);
+        std::vector<Mat> motions(2, Mat(12, 16, 2, SRX_32F));
+        Mat dst2;
+        base.process(src, dst2, motions, 1);
+        REQUIRE(zf->calls == 2 && dst2.rows() == dst.rows());
+        int scale_in_library = 0;
+        REQUIRE(srx_get_int(base.handle(), "scale", &scale_in_library) == SRX_OK && scale_in_library == 2);
+        base.iterations = 0; // the reference debug-asserts iterations > 0 (lib/src/btv_l1.cpp:361)
+        bool threw = false;
+        try
+        {
+            base.process(src, dst2, motions, 1);
+        }
+        catch (const Exception& e)
+        {
+            threw = e.code == SRX_ERR_INVALID;
+        }
+        REQUIRE(threw);
+    }
     // reference spelling: new BTV_L1, set/getInt, setFrameSource, nextFrame (samples/quality_test/main.cpp:255-316)
     BTV_L1 sr(-1);
     REQUIRE(sr.getInt("scale") == 4 && sr.getInt("iterations") == 180 && sr.getInt("btvKernelSize") == 7);
@@ -87,6 +159,22 @@ int main()
         threw = e.code == SRX_ERR_INVALID;
     }
     REQUIRE(threw && sr.getInt("scale") == 4);
+
+    // temporalAreaRadius is a public member (lib/include/super_resolution.hpp:172), read when the stream starts
+    {
+        BTV_L1 direct(-1);
+        direct.temporalAreaRadius = 1;
+        REQUIRE(direct.getInt("temporalAreaRadius") == 1);
+        direct.setOpticalFlow(flow);
+        auto few = std::make_shared<CountingSource>(3); // 2r+1 frames are enough for radius 1, not for radius 4
+        direct.setFrameSource(few);
+        int outs = 0;
+        while (!direct.nextFrame().empty())
+            ++outs;
+        REQUIRE(outs == 3);
+        direct.set("temporalAreaRadius", 2);
+        REQUIRE(direct.temporalAreaRadius == 2);
+    }
 
     // a stream shorter than 2r+1 frames trips the warm-up assertion (lib/src/btv_l1.cpp:479)
     threw = false;

@@ -260,8 +260,18 @@ def test_output_range_restricts_solves_to_the_span():
     assert sorted(got) == sorted(whole)
 
 
-def test_dry_handle_rejects_compute_calls():
+def test_dry_handle_walks_process_and_rejects_compute_calls():
     sr = api.BTV_L1(-1)
+    frames = [np.zeros((6, 8), np.float32)] * 3
+    # process on a dry-run handle: arguments are checked, nothing is computed
+    sr.process(frames, [np.zeros((6, 8, 2), np.float32)] * 2, 0)
     with pytest.raises(L.SrxError):
-        sr.process([np.zeros((6, 8), np.float32)] * 2, [np.zeros((6, 8, 2), np.float32)], 0)
+        sr.process(frames, [np.zeros((6, 9, 2), np.float32)] * 2, 0)
+    # without motions the flow plug-in is asked once per frame other than the base (lib/src/btv_l1.cpp:311-321)
+    calls = []
+    sr.setOpticalFlow(lambda a, b: calls.append(1) or np.zeros((6, 8, 2), np.float32))
+    sr.process(frames, None, 1)
+    assert len(calls) == 2
+    with pytest.raises(L.SrxError):
+        sr.calcFlow(frames[0], frames[1])
     assert L.lib().srx_get_kernel_path() == 0
