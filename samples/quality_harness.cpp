@@ -9,8 +9,20 @@
 // REFLECT_101, then every scale-th pixel, main.cpp:130-131; optional Gaussian + spike noise,
 // :133-134) -> BTV_L1::nextFrame(); metrics of the result against the gold frame cropped by
 // btvKernelSize, and of a bicubic enlargement against the whole gold frame.
-// The bicubic column is computed in float and rounded (cv::resize on 8-bit data uses 11-bit fixed
-// point coefficients; that variant is not reproduced).
+// As there, the first frame of the clip is dropped from all three sources before the loop (main.cpp:273-287).
+//
+// What can be compared with a run of the reference's program on the same clip:
+//  * the metric functions: PSNR is exact (integer sum of squared differences), MSSIM follows the float
+//    operations of main.cpp:140-199 one by one, including the colour case's read of component 3;
+//  * the SuperRes column given the same low-resolution frames and the same motions: the solver is checked bit
+//    for bit against the restatement of lib/src/btv_l1.cpp; with the built-in flows the motions differ from
+//    OpenCV's in the last bits (Farneback and TV-L1 are restated from their published algorithms), so expect
+//    agreement to a few hundredths of a dB, not to the digit.
+// What cannot match to the digit:
+//  * the low-resolution frames themselves: the reference degrades with cv::GaussianBlur on 8-bit data
+//    (main.cpp:130-131), which runs in fixed point; the blur here runs in float and rounds once;
+//  * the BiCubic column: cv::resize on 8-bit data (main.cpp:318) uses 11-bit fixed-point coefficients; here the
+//    enlargement is computed in float and rounded.
 #include <srx/superres.hpp>
 
 #include <cmath>
@@ -211,7 +223,11 @@ int main(int argc, char** argv)
     }
     try
     {
-        Ptr<SuperResolution> superRes = createSuperResolution_BTVL1(0);
+        // the reference's program does `new BTV_L1` / `new BTV_L1_GPU` (main.cpp:255-259); creation by the
+        // registered name reaches the same class
+        if (!initModule_superres())
+            return 1;
+        Ptr<SuperResolution> superRes = Algorithm::create<SuperResolution>("SuperResolution.BTV_L1");
         const int B = superRes->getInt("btvKernelSize");
         superRes->set("scale", scale);
         superRes->set("iterations", iterations);
@@ -221,11 +237,21 @@ int main(int argc, char** argv)
         Ptr<IFrameSource> gold(new GoldSource(rows, cols, ch, frames));
         Ptr<IFrameSource> lowRes(new DegradedSource(Ptr<IFrameSource>(new GoldSource(rows, cols, ch, frames)), scale, noise));
         Ptr<IFrameSource> lowRes2(new DegradedSource(Ptr<IFrameSource>(new GoldSource(rows, cols, ch, frames)), scale, noise));
+        // "skip first frame, it is usually corrupted" (main.cpp:273-287): all three sources drop their first
+        // frame before the super-resolution object sees its source, so the table starts at the clip's second frame
+        {
+            Mat frame = lowRes->nextFrame();
+            frame = lowRes2->nextFrame();
+            frame = gold->nextFrame();
+            if (frame.empty())
+                return 2;
+        }
         superRes->setFrameSource(lowRes);
 
         std::printf("Input             : synthetic %dx%d, %d channel(s), %d frames%s\n", cols, rows, ch, frames,
                     noise ? ", noise" : "");
-        std::printf("Scale factor      : %d\nIterations        : %d\nFrames to process : %d\nOptical Flow      : %s\n\n",
+        std::printf("Scale factor      : %d\nIterations        : %d\nFrames to process : %d\nOptical Flow      : %s\n"
+                    "Mode              : GPU\n\n",
                     scale, iterations, 2 * temporal + 1, optFlow.c_str());
         std::printf("-----------------------------------------------------------------\n");
         std::printf("|   Ind    |  SuperRes PSNR / MSSIM  |   BiCubic PSNR / MSSIM   |\n");

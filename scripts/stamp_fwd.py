@@ -25,9 +25,18 @@ buf = np.zeros(n_waves * 8, dtype=np.uint64)
 rc = lib.srx_debug_stamps(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size))
 assert rc == 0, rc
 t = buf.reshape(n_waves, 8).astype(np.int64)
-names = ["(overwritten)", "compute (issue, gathers, passes)", "put (wait for staged rows, LDS writes)", "barrier", "whole wave"]
+names = ["prologue (first window, first row pass)", "compute (issue, gathers, passes)",
+         "put (wait for staged rows, LDS writes)", "barrier", "whole wave"]
 print(f"{n_waves} waves; ticks summed over the tile's rows: mean / median / p90")
 for i, nm in enumerate(names):
-    if i == 0:
-        continue
-    print(f"  {nm:40s} {t[:, i].mean():9.0f} {np.median(t[:, i]):9.0f} {np.percentile(t[:, i], 90):9.0f}")
+    print(f"  {nm:44s} {t[:, i].mean():9.0f} {np.median(t[:, i]):9.0f} {np.percentile(t[:, i], 90):9.0f}")
+print("by wave of the block (mean ticks): wave, prologue, compute, put, barrier, whole")
+bw = t.reshape(256, 9, 8)
+for w in range(9):
+    print("  ", w, " ".join(f"{bw[:, w, i].mean():9.0f}" for i in range(5)))
+whole = bw[:, :, 4].max(axis=1)
+print("slowest wave per block: mean", whole.mean(), "min", whole.min(), "max", whole.max())
+kinds = np.stack([(bw[:, :, 7] >> (16 * i)) & 0xFFFF for i in range(4)], axis=-1)
+print("rows by kind (mixed, inside, outside, identity), summed over blocks, by wave:")
+for w in range(9):
+    print("  ", w, kinds[:, w, :].sum(axis=0))

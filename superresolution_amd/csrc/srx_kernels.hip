@@ -334,9 +334,10 @@ static_assert(kFwdMx % 4 == 0, "staged columns start at a multiple of four");
 // One flag byte per (LR row, strip) of a frame's group map: kRowInside when every pixel the forward
 // kernel gathers for that row of that strip lies inside its LDS window and no group is "far", so that
 // the kernel may skip the checks; kRowOutside when (nearly) no lane finds its pixels there, so that
-// the kernel goes to global memory right away.  One wave per (strip, LR row); lanes as in the forward
-// kernel.
-constexpr uint8_t kRowMixed = 0, kRowInside = 1, kRowOutside = 2;
+// the kernel goes to global memory right away; kRowIdentity when every group of the row maps its four
+// pixels onto themselves (zero motion: the base frame of a window, a static scene), so that the kernel
+// needs no entry at all.  One wave per (strip, LR row); lanes as in the forward kernel.
+constexpr uint8_t kRowMixed = 0, kRowInside = 1, kRowOutside = 2, kRowIdentity = 3;
 __global__ void k_group_flags(const uint32_t* __restrict__ grp, uint8_t* __restrict__ flags, int H, int W, int strips_x)
 {
     const int w = W >> 2, h = H >> 2;
@@ -345,12 +346,13 @@ __global__ void k_group_flags(const uint32_t* __restrict__ grp, uint8_t* __restr
     const int xl = min(max(x0 - 1 + lane, 0), w - 1);
     const int dc_lane = 4 * xl - (4 * (x0 - 1) - kFwdMx);
     const size_t entries = (size_t)h * w * 4;
-    bool ok = true, any = false;
+    bool ok = true, any = false, same = true;
     for (int r = 0; r < 4; ++r)
     {
         const size_t e = ((size_t)y * w + xl) * 4 + r;
         const uint32_t w0 = grp[e];
         const int w1 = (int)grp[entries + e];
+        same = same && w0 == 0u && w1 == 0;
         const int dr = __builtin_amdgcn_sbfe((int)w0, 15, 15) + kFwdMy + 1 + r;
         const int dc = __builtin_amdgcn_sbfe((int)w0, 0, 15) + dc_lane;
         bool in = (w0 & kGrpFar) == 0 && (unsigned)dr < (unsigned)kFwdSpan && (unsigned)dc < (unsigned)(4 * kFwdQuads);
@@ -364,9 +366,11 @@ __global__ void k_group_flags(const uint32_t* __restrict__ grp, uint8_t* __restr
         any = any || in;
     }
     const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
+    const bool all_same = all_ok && __builtin_amdgcn_ballot_w64(!same) == 0;
     const int n_in = __builtin_popcountll(__builtin_amdgcn_ballot_w64(any));
     if (lane == 0)
-        flags[(size_t)y * strips_x + strip] = all_ok ? kRowInside : (n_in < 16 ? kRowOutside : kRowMixed);
+        flags[(size_t)y * strips_x + strip] =
+            all_same ? kRowIdentity : (all_ok ? kRowInside : (n_in < 16 ? kRowOutside : kRowMixed));
 }
 
 // ps == 0: interleaved destination; otherwise planar with plane stride ps
@@ -960,28 +964,37 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
     }
 
     // Pieces of this thread within a batch of four HR rows (fixed for the whole tile).  Blocks of
-    // many waves (the common case) own at most two pieces per batch and load them a whole LR row
+    // many waves (the common case) own at most kSlots pieces per batch and load them a whole LR row
     // before they are written to LDS; blocks of few waves stage piece by piece.
-    const bool early = 2 * nthreads >= 4 * kItemsPerRow;
-    int p_rr[2], p_lds[2];
-    size_t p_src[2];
-    bool p_own[2], p_col[2];
+    // The waves of a block are dealt to the CU's four SIMDs in turn, so in a block of 4n+1 waves those
+    // numbered 0, 4, 8 ... share one SIMD that carries a wave more than the others, and the block moves
+    // at that SIMD's pace (one barrier per LR row): these waves take no part in the staging.
+    constexpr int kSlots = 3;
+    const int nwaves = nthreads >> 6, wv = tid >> 6;
+    const bool skew = nwaves > 1 && (nwaves & 3) == 1;
+    const bool stager = !skew || (wv & 3) != 0;
+    const int n_st = skew ? nthreads - 64 * ((nwaves + 3) >> 2) : nthreads;
+    const int stid = skew ? tid - 64 * ((wv >> 2) + 1) : tid;
+    const bool early = kSlots * n_st >= 4 * kItemsPerRow;
+    int p_rr[kSlots], p_lds[kSlots];
+    size_t p_src[kSlots];
+    bool p_own[kSlots], p_col[kSlots];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < kSlots; ++i)
     {
-        const int item = tid + i * nthreads;
+        const int item = max(stid, 0) + i * n_st;
         const int rr_ = item / kItemsPerRow, rem = item - rr_ * kItemsPerRow;
         const int c = rem / kFwdQuads, q = rem - c * kFwdQuads;
         const int col = c0 + 4 * q;
-        p_own[i] = early && item < 4 * kItemsPerRow;
+        p_own[i] = early && stager && item < 4 * kItemsPerRow;
         p_col[i] = (unsigned)col < (unsigned)W;
         p_rr[i] = rr_;
         p_lds[i] = c * kFwdRowBytes + 4 * q;
         p_src[i] = c * ps + (size_t)(p_col[i] ? col : 0);
     }
-    auto batch_load = [&](int row_first, float4 (&v)[2]) {
+    auto batch_load = [&](int row_first, float4 (&v)[kSlots]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < kSlots; ++i)
         {
             const int row = row_first + p_rr[i];
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -989,9 +1002,9 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
                 v[i] = *(const float4*)(X + p_src[i] + (size_t)row * W);
         }
     };
-    auto batch_put = [&](int slot_first, const float4 (&v)[2]) {
+    auto batch_put = [&](int slot_first, const float4 (&v)[kSlots]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < kSlots; ++i)
             if (p_own[i])
             {
                 int slot = slot_first + p_rr[i];
@@ -1152,9 +1165,9 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
     };
 
     float rr[5][CH];
-    uint2 mc[4];
     const int ya = max(y0 - 1, 0);
     const uint2 m0 = make_uint2(((const uint32_t*)(grp0 + (size_t)ya * w))[3], ((const uint32_t*)(grp1 + (size_t)ya * w))[3]);
+    uint2 mc[4];
     load_groups(y0, mc);
     __syncthreads();
     {
@@ -1168,28 +1181,67 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
     }
 
     // The rows that LR row y+1 adds to the window, its map entries and its LR pixel are loaded at
-    // the top of row y and used at its end / in row y+1.
+    // the top of row y and used at its end / in row y+1.  (Loading entries two rows ahead into alternating
+    // register sets was tried and is slower: with loads under branches in the loop the compiler's wait counts
+    // at the joins fall back to "all loads done", which puts the whole memory latency in front of every row.)
     int s = 0; // ring slot of the first row of the current LR row's window
     packed_floats<CH> yv = *(const packed_floats<CH>*)(yk + (size_t)y0 * w * CH);
-    uint8_t place = flags[(size_t)y0 * strips_x];
+    // The kinds of the tile's rows, 64 rows at a time, one per lane: a load per row would put a memory
+    // latency in front of every row (the kind decides the row's code path).
+    uint32_t kinds = flags[(size_t)min(y0 + lane, h - 1) * strips_x];
+    uint8_t place = (uint8_t)__builtin_amdgcn_readlane((int)kinds, 0);
     uint32_t sg_above = 0; // sign word of the LR row before the current one
 #ifdef SRX_STAMPS
     unsigned long long t_compute = 0, t_put = 0, t_barrier = 0, t_prologue = SRX_TICK() - t_begin;
+    unsigned n_place[4] = {0, 0, 0, 0};
 #endif
     for (int y = y0; y < y1; ++y)
     {
 #ifdef SRX_STAMPS
         const unsigned long long t_a = SRX_TICK();
+        ++n_place[place & 3];
 #endif
         const bool more = y + 1 < y1;
-        const uint8_t place_next = flags[(size_t)min(y + 1, h - 1) * strips_x];
-        float4 sv[2];
+        const int ahead = y + 1 - y0; // row y + 1 within the tile
+        if ((ahead & 63) == 0)
+            kinds = flags[(size_t)min(y + 1 + lane, h - 1) * strips_x];
+        const uint8_t place_next = (uint8_t)__builtin_amdgcn_readlane((int)kinds, ahead & 63);
+        float4 sv[kSlots];
         batch_load(more ? 4 * y + 3 + kFwdMy : H, sv);
         uint2 mn[4];
         load_groups(min(y + 1, h - 1), mn);
         const packed_floats<CH> yn = *(const packed_floats<CH>*)(yk + (size_t)min(y + 1, h - 1) * w * CH);
 
-        if (place == kRowOutside)
+        if (place == kRowIdentity)
+        {
+            // zero motion: pixel j of the group is element dc_lane + j of its own row, i.e. entry dc_lane / 4
+            // of sub-array j - one address per row, everything else is in the instructions' offsets
+            float4 a[4][CH];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+                int slot = s + kFwdMy + 1 + r;
+                slot = slot >= kFwdRing ? slot - kFwdRing : slot;
+                const unsigned at = (unsigned)(slot * kSlotBytes) + (unsigned)dc_lane;
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                {
+                    a[r][c].x = *(lds_cfloat*)(uintptr_t)(at + c * kFwdRowBytes);
+                    a[r][c].y = *(lds_cfloat*)(uintptr_t)(at + c * kFwdRowBytes + 4 * kFwdQuads);
+                    a[r][c].z = *(lds_cfloat*)(uintptr_t)(at + c * kFwdRowBytes + 8 * kFwdQuads);
+                    a[r][c].w = *(lds_cfloat*)(uintptr_t)(at + c * kFwdRowBytes + 12 * kFwdQuads);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    a[r][c].w = mirror ? a[r][c].y : a[r][c].w;
+                row_pass(a[r], rr[r + 1]);
+            }
+        }
+        else if (place != kRowInside)
         {
             float4 a[4][CH];
             fetch_global_rows(mc, 4 * y - 1, a);
@@ -1197,7 +1249,7 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
             for (int r = 0; r < 4; ++r)
                 row_pass(a[r], rr[r + 1]);
         }
-        else if (place == kRowInside)
+        else
         {
             // all LDS reads of the LR row in flight before the first row pass
             float4 a[4][CH];
@@ -1207,17 +1259,6 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 row_pass(a[r], rr[r + 1]);
-        }
-        else
-        {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-            {
-                float4 a[CH];
-                if (!fetch(mc[r], kFwdMy + 1 + r, s, true, a))
-                    fetch_global(mc[r], 4 * y - 1 + r, a);
-                row_pass(a, rr[r + 1]);
-            }
         }
         place = place_next;
 
@@ -1274,6 +1315,13 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
     }
 #ifdef SRX_STAMPS
     SRX_FWD_STAMPS(t_prologue, t_compute, t_put, t_barrier, SRX_TICK() - t_begin);
+    if ((threadIdx.x & 63) == 0)
+    {
+        const unsigned wave_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (wave_ < (1u << 16)) // rows by kind, 16 bits each: mixed, inside, outside, identity
+            g_stamps[wave_ * kStampSlots + 7] = n_place[0] | ((unsigned long long)n_place[1] << 16) |
+                                                ((unsigned long long)n_place[2] << 32) | ((unsigned long long)n_place[3] << 48);
+    }
 #endif
 }
 

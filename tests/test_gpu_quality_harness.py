@@ -21,7 +21,7 @@ def test_super_resolution_beats_bicubic(channels, flow):
     assert r.returncode == 0, r.stdout + r.stderr
     rows = re.findall(r"\|\s+\[\s*(\d+)\]\s+\|\s+([\d.]+) / ([\d.]+)\s+\|\s+([\d.]+) / ([\d.]+)", r.stdout)
     assert "Optical Flow      : " + flow in r.stdout
-    assert len(rows) == 9                     # one output per input frame
+    assert len(rows) == 8                     # one output per input frame after the skipped first one (main.cpp:273-287)
     sr = sum(float(x[1]) for x in rows) / len(rows)
     bc = sum(float(x[3]) for x in rows) / len(rows)
     assert sr > bc + 1.0, r.stdout            # at least 1 dB over bicubic on this clip
