@@ -513,7 +513,8 @@ def bench_tvl1(args):
                 "step_ms": [round(v, 2) for v in step_ms],
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_tvl1_iter4 (all levels; one launch per inner iteration)",
+                "bound": "hbm", "kernel": "k_tvl1_iter4 on levels of a megapixel and more (one inner iteration per launch), "
+                                           "k_tvl1_multi below (4 or 8 inner iterations per launch)",
                 "achieved": bytes_pair / per_pair_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": bytes_pair / per_pair_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_bytes_per_pair": bytes_pair,

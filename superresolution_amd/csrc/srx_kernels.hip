@@ -320,8 +320,10 @@ __global__ void k_group_maps(const short2* __restrict__ bwd_map, uint32_t* __res
 
 // Geometry of the forward kernel's LDS window (described above k_forward_sign_lds)
 constexpr int kFwdStrip = 63;
-constexpr int kFwdRing = 40;
-constexpr int kFwdMy = 15;
+// 47 rows of three planes fill the CU's 160 KB: motions of up to 19 HR rows either way stay in the window
+// (with 40 rows / 15, windows of the benchmark clip whose corners move by 16 to 21 rows cost 15 % more)
+constexpr int kFwdRing = 47;
+constexpr int kFwdMy = 19;
 constexpr int kFwdMx = 16;
 constexpr int kFwdQuads = kFwdStrip + 1 + kFwdMx / 2; // 16-byte groups per staged row
 constexpr int kFwdRowBytes = 16 * kFwdQuads;          // one row of one plane

@@ -566,6 +566,183 @@ __global__ __launch_bounds__(256) void k_tvl1_iter4(Tvl1Planes P, int rows, int 
         atomicAdd(&err[it], part[0] + part[1] + part[2] + part[3]);
 }
 
+// Several inner iterations in one launch.  A block owns a tile of TW x TH pixels and loads it with a halo of
+// KT pixels on every side; each iteration is carried out on the whole region held by the block, and what a
+// pixel at the region's edge cannot know (its neighbour lies outside) makes the outermost ring of the region
+// wrong by one pixel more per iteration - after KT iterations the tile itself is still exact.  Every value of
+// the tile is computed by the same float operations, from the same operands, as by one launch per iteration
+// (k_tvl1_iter); only pixels of the halo are computed more than once, by the blocks that share them.
+//   state per pixel: u1, u2, p11, p12, p21, p22 and the four constants of the warp, in registers;
+//   LDS: p11, p21 (read by the right neighbour), p12, p22 (by the lower one), new u1, u2 (by the left and
+//   upper ones for the forward gradient) of the whole region.
+// Launch b covers iterations it0 = b*KT .. it0+n_iter-1, reads buffer set b & 1 and writes the other one, and
+// adds each iteration's error over its tile to err[it].  The iteration stops after the first iteration j whose
+// error is at most thr (lib side: the published TV-L1 loop "while (error > epsilon^2 * area && n < iterations)").
+// A launch therefore looks at the errors of all earlier iterations first:
+//   none at or below thr: it runs;
+//   the first such j is the last iteration of the launch before: done, the result is what that launch wrote
+//   (the set this launch would read); it returns, as do all launches after it;
+//   the first such j lies inside the launch before, not at its end: that launch ran too far.  Its input set
+//   is still intact (this launch is the only one that would overwrite it), so this launch repeats the
+//   iterations up to j from that set and writes the result over the other one - the same set as in the case
+//   above - without touching err[];
+//   j is older than that: it returns.
+template <int KT, int TW, int TH>
+__global__ __launch_bounds__(256) void k_tvl1_multi(Tvl1Planes P, int rows, int cols, float l_t, float theta,
+                                                     float taut, unsigned long long* __restrict__ err, int n_err,
+                                                     int it0, int n_iter, unsigned long long thr)
+{
+    constexpr int RW = TW + 2 * KT, RH = TH + 2 * KT, CELLS = RW * RH, PER = (CELLS + 255) / 256;
+    __shared__ float s_p11[CELLS], s_p21[CELLS], s_p12[CELLS], s_p22[CELLS], s_u1[CELLS], s_u2[CELLS];
+    __shared__ unsigned long long s_err[KT][4];
+    __shared__ int s_first;
+    const int tid = threadIdx.x;
+    if (tid < 64)
+    {
+        int first = 0x7FFFFFFF;
+        for (int j = tid; j < min(it0, n_err); j += 64) // err[] has n_err entries
+            if (err[j] <= thr)
+            {
+                first = j;
+                break;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            first = min(first, __shfl_down(first, o, 64));
+        if (tid == 0)
+            s_first = first;
+    }
+    __syncthreads();
+    const int first = s_first;
+    bool redo = false;
+    if (first != 0x7FFFFFFF)
+    {
+        if (first < it0 - KT || first == it0 - 1)
+            return;
+        redo = true;
+        n_iter = first - (it0 - KT) + 1;
+    }
+    // the sets as this launch uses them (a repeat reads what the launch before read)
+    const float* ru1 = redo ? P.nu1 : P.u1;
+    const float* ru2 = redo ? P.nu2 : P.u2;
+    const float* rp11 = redo ? P.np11 : P.p11;
+    const float* rp12 = redo ? P.np12 : P.p12;
+    const float* rp21 = redo ? P.np21 : P.p21;
+    const float* rp22 = redo ? P.np22 : P.p22;
+    float* wu1 = redo ? const_cast<float*>(P.u1) : P.nu1;
+    float* wu2 = redo ? const_cast<float*>(P.u2) : P.nu2;
+    float* wp11 = redo ? const_cast<float*>(P.p11) : P.np11;
+    float* wp12 = redo ? const_cast<float*>(P.p12) : P.np12;
+    float* wp21 = redo ? const_cast<float*>(P.p21) : P.np21;
+    float* wp22 = redo ? const_cast<float*>(P.p22) : P.np22;
+
+    const int x0 = blockIdx.x * TW - KT, y0 = blockIdx.y * TH - KT; // image position of the region's first cell
+    float cgx[PER], cgy[PER], cg[PER], crc[PER], a[PER], b[PER], q11[PER], q12[PER], q21[PER], q22[PER];
+    bool inside[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+    {
+        const int c = tid + 256 * i;
+        const int cy = c / RW, cx = c - cy * RW;
+        const int gx = x0 + cx, gy = y0 + cy;
+        inside[i] = c < CELLS && gx >= 0 && gx < cols && gy >= 0 && gy < rows;
+        cgx[i] = cgy[i] = cg[i] = crc[i] = a[i] = b[i] = q11[i] = q12[i] = q21[i] = q22[i] = 0.0f;
+        if (inside[i])
+        {
+            const size_t o = (size_t)gy * cols + gx;
+            cgx[i] = P.I1wx[o], cgy[i] = P.I1wy[o], cg[i] = P.grad[o], crc[i] = P.rho_c[o];
+            a[i] = ru1[o], b[i] = ru2[o];
+            q11[i] = rp11[o], q12[i] = rp12[o], q21[i] = rp21[o], q22[i] = rp22[o];
+        }
+        if (c < CELLS)
+            s_p11[c] = q11[i], s_p21[c] = q21[i], s_p12[c] = q12[i], s_p22[c] = q22[i];
+    }
+    unsigned long long e[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+        e[j] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+    {
+        if (j < n_iter) // the same for every thread of the block
+        {
+#pragma unroll
+            for (int i = 0; i < PER; ++i)
+            {
+                const int c = tid + 256 * i;
+                if (!inside[i])
+                    continue;
+                const int cy = c / RW, cx = c - cy * RW;
+                const int gx = x0 + cx, gy = y0 + cy;
+                const float l11 = cx > 0 ? s_p11[c - 1] : 0.0f, l21 = cx > 0 ? s_p21[c - 1] : 0.0f;
+                const float u12 = cy > 0 ? s_p12[c - RW] : 0.0f, u22 = cy > 0 ? s_p22[c - RW] : 0.0f;
+                float n1, n2;
+                tvl1_u_values(cgx[i], cgy[i], cg[i], crc[i], a[i], b[i], q11[i], q12[i], q21[i], q22[i], l11, l21, u12,
+                              u22, gx > 0, gy > 0, l_t, theta, n1, n2);
+                if (cx >= KT && cx < KT + TW && cy >= KT && cy < KT + TH)
+                    e[j] += error_term(n1 - a[i], n2 - b[i]);
+                a[i] = n1, b[i] = n2;
+                s_u1[c] = n1, s_u2[c] = n2;
+            }
+        }
+        __syncthreads();
+        if (j < n_iter)
+        {
+#pragma unroll
+            for (int i = 0; i < PER; ++i)
+            {
+                const int c = tid + 256 * i;
+                if (!inside[i])
+                    continue;
+                const int cy = c / RW, cx = c - cy * RW;
+                const int gx = x0 + cx, gy = y0 + cy;
+                const bool has_r = gx < cols - 1, has_d = gy < rows - 1;
+                const float n1 = a[i], n2 = b[i];
+                const float r1 = cx + 1 < RW ? s_u1[c + 1] : 0.0f, r2 = cx + 1 < RW ? s_u2[c + 1] : 0.0f;
+                const float d1 = cy + 1 < RH ? s_u1[c + RW] : 0.0f, d2 = cy + 1 < RH ? s_u2[c + RW] : 0.0f;
+                const float u1x = has_r ? r1 - n1 : 0.0f, u1y = has_d ? d1 - n1 : 0.0f;
+                const float u2x = has_r ? r2 - n2 : 0.0f, u2y = has_d ? d2 - n2 : 0.0f;
+                const float g1 = sqrtf(u1x * u1x + u1y * u1y), g2 = sqrtf(u2x * u2x + u2y * u2y);
+                const float ng1 = 1.0f + taut * g1, ng2 = 1.0f + taut * g2;
+                q11[i] = (q11[i] + taut * u1x) / ng1;
+                q12[i] = (q12[i] + taut * u1y) / ng1;
+                q21[i] = (q21[i] + taut * u2x) / ng2;
+                q22[i] = (q22[i] + taut * u2y) / ng2;
+                s_p11[c] = q11[i], s_p21[c] = q21[i], s_p12[c] = q12[i], s_p22[c] = q22[i];
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+    {
+        const int c = tid + 256 * i;
+        const int cy = c / RW, cx = c - cy * RW;
+        if (inside[i] && cx >= KT && cx < KT + TW && cy >= KT && cy < KT + TH)
+        {
+            const size_t o = (size_t)(y0 + cy) * cols + (x0 + cx);
+            wu1[o] = a[i], wu2[o] = b[i];
+            wp11[o] = q11[i], wp12[o] = q12[i], wp21[o] = q21[i], wp22[o] = q22[i];
+        }
+    }
+    if (redo)
+        return;
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+    {
+        unsigned long long v = e[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            v += __shfl_down(v, o, 64);
+        if ((tid & 63) == 0)
+            s_err[j][tid >> 6] = v;
+    }
+    __syncthreads();
+    if (tid < KT && tid < n_iter)
+        atomicAdd(&err[it0 + tid], s_err[tid][0] + s_err[tid][1] + s_err[tid][2] + s_err[tid][3]);
+}
+
 // cv::resize(INTER_LINEAR) of the two flow planes to the next finer level, times 2
 __global__ void k_upsample_flow(const float* __restrict__ s1, const float* __restrict__ s2, int srows, int scols,
                                 float* __restrict__ d1, float* __restrict__ d2, int drows, int dcols)
@@ -790,33 +967,59 @@ int Tvl1::calc_gray(const float* I0, const float* I1, int rows, int cols, const 
             int done = iters; // iterations that ran
             float* ua[2][2] = {{L.u1.as<float>(), L.u2.as<float>()}, {m.u_alt.as<float>(), m.u_alt.as<float>() + n}};
             float* pa[2] = {p11, m.p_alt.as<float>()};
-            const dim3 bi(kItX, kItY);
-            const dim3 gi = grid2(C, R, bi);
             int& predicted = m.last_done[(size_t)s * p.warps + w];
-            for (int it0 = 0, it1 = 0; it0 < iters; it0 = it1)
-            {
-                const int batch = it0 == 0 && predicted > 0 ? std::min(predicted + 1, kPollStride) : kPollRest;
-                it1 = std::min(it0 + batch, iters);
-                for (int it = it0; it < it1; ++it)
+            // 0: at most 200 000 pixels, 1: at most 1 000 000, 2: more
+            const int size_class = n > (size_t)1000000 ? 2 : (n > (size_t)200000 ? 1 : 0);
+            // Iterations per launch.  Small levels are bound by the time a launch takes whatever it does: 8 iterations
+            // on tiles of 16 x 16.  Levels of a megapixel and more are bound by memory traffic, and the short row
+            // segments of a tile with halo waste too much of every cache line: one iteration per launch on tiles
+            // of 128 x 8 with 16-byte accesses stays the fastest there (40 us per iteration at 1920 x 1080 against
+            // 59 us per iteration for 2 iterations per launch on 32 x 32, 48 us on 128 x 8).
+            const int kt = size_class == 2 ? 1 : (size_class == 1 ? 4 : 8);
+            const int tw = size_class == 0 ? 16 : 32, th = tw;
+            const int n_launch = (iters + kt - 1) / kt;
+            const dim3 gm((C + tw - 1) / tw, (R + th - 1) / th);
+            auto enqueue = [&](int bidx) {
+                const int src = bidx & 1, dst = src ^ 1;
+                Tvl1Planes P;
+                P.I1wx = m.I1wx.as<float>(), P.I1wy = m.I1wy.as<float>(), P.grad = m.grad.as<float>();
+                P.rho_c = m.rho_c.as<float>();
+                P.u1 = ua[src][0], P.u2 = ua[src][1];
+                P.p11 = pa[src], P.p12 = pa[src] + n, P.p21 = pa[src] + 2 * n, P.p22 = pa[src] + 3 * n;
+                P.nu1 = ua[dst][0], P.nu2 = ua[dst][1];
+                P.np11 = pa[dst], P.np12 = pa[dst] + n, P.np21 = pa[dst] + 2 * n, P.np22 = pa[dst] + 3 * n;
+                // (a launch past the last iteration only ever repairs the one before it)
+                const int first = bidx * kt, count = std::max(0, std::min(kt, iters - first));
+                if (size_class == 2) // one iteration per launch: launch `bidx` is iteration `bidx`
                 {
-                    const int src = it & 1, dst = src ^ 1;
-                    Tvl1Planes P;
-                    P.I1wx = m.I1wx.as<float>(), P.I1wy = m.I1wy.as<float>(), P.grad = m.grad.as<float>();
-                    P.rho_c = m.rho_c.as<float>();
-                    P.u1 = ua[src][0], P.u2 = ua[src][1];
-                    P.p11 = pa[src], P.p12 = pa[src] + n, P.p21 = pa[src] + 2 * n, P.p22 = pa[src] + 3 * n;
-                    P.nu1 = ua[dst][0], P.nu2 = ua[dst][1];
-                    P.np11 = pa[dst], P.np12 = pa[dst] + n, P.np21 = pa[dst] + 2 * n, P.np22 = pa[dst] + 3 * n;
                     if (C % 4 == 0)
-                        hipLaunchKernelGGL(k_tvl1_iter4, grid2(C, R, dim3(kIt4X, kIt4Y)), dim3(32, kIt4Y), 0, st, P, R,
-                                           C, l_t, theta, taut, m.err.as<unsigned long long>(), it, thr);
+                        hipLaunchKernelGGL(k_tvl1_iter4, grid2(C, R, dim3(kIt4X, kIt4Y)), dim3(32, kIt4Y), 0, st, P, R, C,
+                                           l_t, theta, taut, m.err.as<unsigned long long>(), bidx, thr);
                     else
-                        hipLaunchKernelGGL(k_tvl1_iter, gi, bi, 0, st, P, R, C, l_t, theta, taut,
-                                           m.err.as<unsigned long long>(), it, thr);
+                        hipLaunchKernelGGL(k_tvl1_iter, grid2(C, R, dim3(kItX, kItY)), dim3(kItX, kItY), 0, st, P, R, C,
+                                           l_t, theta, taut, m.err.as<unsigned long long>(), bidx, thr);
                 }
-                SRX_LAUNCH_CHECK("tvl1 iteration");
-                // the queued kernels already stop by themselves on the device; looking at the error here only
-                // saves enqueueing launches that would return at once
+                else if (size_class == 1)
+                    hipLaunchKernelGGL((k_tvl1_multi<4, 32, 32>), gm, dim3(256), 0, st, P, R, C, l_t, theta, taut,
+                                       m.err.as<unsigned long long>(), iters, first, count, thr);
+                else
+                    hipLaunchKernelGGL((k_tvl1_multi<8, 16, 16>), gm, dim3(256), 0, st, P, R, C, l_t, theta, taut,
+                                       m.err.as<unsigned long long>(), iters, first, count, thr);
+            };
+            // Launches are queued in batches; the error values are looked at after each batch.  The queued
+            // launches stop by themselves on the device (and repair a launch that ran too far); looking here
+            // only saves queueing launches that would return at once.  The batch sizes follow the number of
+            // iterations the same level and warp took for the previous pair.
+            int last_launch = n_launch - 1; // the launch whose output set holds the result
+            for (int b0 = 0, b1 = 0; b0 < n_launch; b0 = b1)
+            {
+                const int batch = b0 == 0 && predicted > 0 ? std::min((predicted + kt - 1) / kt + 1, kPollStride / kt + 1)
+                                                           : std::max(kPollRest / kt, 2);
+                b1 = std::min(b0 + batch, n_launch);
+                for (int bidx = b0; bidx < b1; ++bidx)
+                    enqueue(bidx);
+                SRX_LAUNCH_CHECK("tvl1 iterations");
+                const int it0 = b0 * kt, it1 = std::min(b1 * kt, iters);
                 SRX_HIP(hipMemcpyAsync(herr + it0, m.err.as<unsigned long long>() + it0,
                                        (size_t)(it1 - it0) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
                 SRX_HIP(hipStreamSynchronize(st));
@@ -828,11 +1031,21 @@ int Tvl1::calc_gray(const float* I0, const float* I1, int rows, int cols, const 
                         stop = true;
                     }
                 if (stop)
+                {
+                    last_launch = (done - 1) / kt;
+                    // a launch that ran past the last iteration is repaired by the launch after it
+                    if (done % kt != 0 && done != iters && last_launch + 1 >= b1)
+                    {
+                        enqueue(last_launch + 1);
+                        SRX_LAUNCH_CHECK("tvl1 iterations (repeat)");
+                    }
                     break;
+                }
             }
-            if (done & 1)
+            const bool in_second_set = ((last_launch + 1) & 1) != 0;
+            if (in_second_set)
             {
-                // an odd number of iterations leaves the result in the second buffer set
+                // an odd number of launches leaves the result in the second buffer set
                 SRX_HIP(hipMemcpyAsync(ua[0][0], ua[1][0], n * sizeof(float), hipMemcpyDeviceToDevice, st));
                 SRX_HIP(hipMemcpyAsync(ua[0][1], ua[1][1], n * sizeof(float), hipMemcpyDeviceToDevice, st));
                 SRX_HIP(hipMemcpyAsync(pa[0], pa[1], 4 * n * sizeof(float), hipMemcpyDeviceToDevice, st));
