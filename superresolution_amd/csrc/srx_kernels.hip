@@ -99,14 +99,21 @@ namespace
 //                left and top edges, which therefore need no entries of their
 //                own); 25 = all weights 0 (target outside the image, or in the
 //                last column / row, whose only tap is a reflected one)
-// group map entry of the backward map, for the sources (col_i, row_i), i = 0..3, of 4 neighbouring
+// group map entry of the backward map: one word for the sources (col_i, row_i), i = 0..3, of 4 neighbouring
 // pixels of HR row N = 4y-1+r (the map row itself is the reflected one at the top edge), columns 4x..4x+3:
-//   word 0  bits 0..14 col_0 - 4x, bits 15..29 row_0 - N, both signed;
-//           bit 30: "far" - some coordinate does not fit its field (read the raw map instead)
-//   word 1  for i = 1..3, at bit 10(i-1): col_i - (col_0 + i) (5 bits, signed), then row_i - row_0
-//           (5 bits, signed); all zero when the four sources are one run of pixels
+//   bits 0..8   col_0 - 4x, bits 9..17 row_0 - N, both signed (-256 .. 255);
+//   for i = 1..3, at bit 18 + 4(i-1): col_i - (col_0 + i) (2 bits, signed: -2 .. 1), then row_i - row_0
+//               (2 bits, signed); all zero when the four sources are one run of pixels;
+//   bit 30      "far" - some coordinate does not fit its field (read the raw map instead)
+// Four entries (r = 0..3) per LR pixel, 16 bytes: half of what the raw map takes for the same 16 pixels.
 // Sources outside the image keep their coordinates: the forward kernel stages zeros around the image.
 constexpr uint32_t kGrpFar = 1u << 30;
+constexpr uint32_t kGrpRowBits = 0x33300000u;   // the three row_i - row_0 fields
+constexpr uint32_t kGrpOtherBits = 0x3FFC0000u; // all fields of pixels 1..3
+__device__ __forceinline__ int grp_dc(uint32_t g) { return __builtin_amdgcn_sbfe((int)g, 0, 9); }
+__device__ __forceinline__ int grp_dr(uint32_t g) { return __builtin_amdgcn_sbfe((int)g, 9, 9); }
+__device__ __forceinline__ int grp_dx(uint32_t g, int j) { return __builtin_amdgcn_sbfe((int)g, 18 + 4 * (j - 1), 2); }
+__device__ __forceinline__ int grp_dy(uint32_t g, int j) { return __builtin_amdgcn_sbfe((int)g, 20 + 4 * (j - 1), 2); }
 constexpr int kGrpMaxDim = 16383; // displacements must fit 15 signed bits
 constexpr uint32_t kFwdCellMask = 0x00FFFFFFu;
 constexpr int kFwdLutShift = 24;
@@ -305,17 +312,16 @@ __global__ void k_group_maps(const short2* __restrict__ bwd_map, uint32_t* __res
     const int N = 4 * y - 1 + r;
     const short2* m = bwd_map + (size_t)reflect101(N, H) * W + 4 * x;
     const int col0 = m[0].x, row0 = m[0].y;
-    const int ddx = clampi(col0 - 4 * x, -16384, 16383), ddy = clampi(row0 - N, -16384, 16383);
+    const int ddx = clampi(col0 - 4 * x, -256, 255), ddy = clampi(row0 - N, -256, 255);
     bool far = ddx != col0 - 4 * x || ddy != row0 - N;
-    uint32_t w1 = 0;
+    uint32_t others = 0;
     for (int i = 1; i <= 3; ++i)
     {
         const int dx = m[i].x - (col0 + i), dy = m[i].y - row0;
-        far = far || dx < -16 || dx > 15 || dy < -16 || dy > 15;
-        w1 |= ((uint32_t)(dx & 31) | ((uint32_t)(dy & 31) << 5)) << (10 * (i - 1));
+        far = far || dx < -2 || dx > 1 || dy < -2 || dy > 1;
+        others |= ((uint32_t)(dx & 3) | ((uint32_t)(dy & 3) << 2)) << (4 * (i - 1));
     }
-    grp[e] = ((uint32_t)ddx & 0x7FFFu) | (((uint32_t)ddy & 0x7FFFu) << 15) | (far ? kGrpFar : 0u);
-    grp[entries + e] = w1;
+    grp[e] = ((uint32_t)ddx & 0x1FFu) | (((uint32_t)ddy & 0x1FFu) << 9) | (others << 18) | (far ? kGrpFar : 0u);
 }
 
 // Geometry of the forward kernel's LDS window (described above k_forward_sign_lds)
@@ -342,26 +348,24 @@ static_assert(kFwdMx % 4 == 0, "staged columns start at a multiple of four");
 constexpr uint8_t kRowMixed = 0, kRowInside = 1, kRowOutside = 2, kRowIdentity = 3;
 __global__ void k_group_flags(const uint32_t* __restrict__ grp, uint8_t* __restrict__ flags, int H, int W, int strips_x)
 {
-    const int w = W >> 2, h = H >> 2;
+    const int w = W >> 2;
     const int strip = blockIdx.x, y = blockIdx.y, lane = threadIdx.x;
     const int x0 = strip * kFwdStrip;
     const int xl = min(max(x0 - 1 + lane, 0), w - 1);
     const int dc_lane = 4 * xl - (4 * (x0 - 1) - kFwdMx);
-    const size_t entries = (size_t)h * w * 4;
     bool ok = true, any = false, same = true;
     for (int r = 0; r < 4; ++r)
     {
         const size_t e = ((size_t)y * w + xl) * 4 + r;
         const uint32_t w0 = grp[e];
-        const int w1 = (int)grp[entries + e];
-        same = same && w0 == 0u && w1 == 0;
-        const int dr = __builtin_amdgcn_sbfe((int)w0, 15, 15) + kFwdMy + 1 + r;
-        const int dc = __builtin_amdgcn_sbfe((int)w0, 0, 15) + dc_lane;
+        same = same && w0 == 0u;
+        const int dr = grp_dr(w0) + kFwdMy + 1 + r;
+        const int dc = grp_dc(w0) + dc_lane;
         bool in = (w0 & kGrpFar) == 0 && (unsigned)dr < (unsigned)kFwdSpan && (unsigned)dc < (unsigned)(4 * kFwdQuads);
         for (int j = 1; j < 4; ++j)
         {
-            const int drj = dr + __builtin_amdgcn_sbfe(w1, 10 * (j - 1) + 5, 5);
-            const int e_ = dc + j + __builtin_amdgcn_sbfe(w1, 10 * (j - 1), 5);
+            const int drj = dr + grp_dy(w0, j);
+            const int e_ = dc + j + grp_dx(w0, j);
             in = in && (unsigned)drj < (unsigned)kFwdSpan && (unsigned)e_ < (unsigned)(4 * kFwdQuads);
         }
         ok = ok && in;
@@ -918,9 +922,8 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
     const int dc_lane = 4 * xl - c0;
 
     const uint4* grp0 = (const uint4*)grp_bwd.p[k] + xl;
-    const uint4* grp1 = grp0 + (size_t)h * w;
     // per LR row: 1 = every gather of this strip's row stays inside the window (k_group_flags)
-    const uint8_t* flags = (const uint8_t*)((const uint32_t*)grp_bwd.p[k] + (size_t)H * W / 2) + strip;
+    const uint8_t* flags = (const uint8_t*)((const uint32_t*)grp_bwd.p[k] + (size_t)H * W / 4) + strip;
     const float* yk = (const float*)ys.p[k] + (size_t)xl * CH;
     uint32_t* sp = (uint32_t*)signs.p[k] + 2 * (size_t)xl;
     const float k0 = g.k[2], k1 = g.k[3], k2 = g.k[4];
@@ -1016,22 +1019,20 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
             }
     };
 
-    auto load_groups = [&](int y, uint2 (&m)[4]) {
-        const uint4 a0 = stream_load(grp0 + (size_t)y * w), a1 = stream_load(grp1 + (size_t)y * w);
-        m[0] = make_uint2(a0.x, a1.x), m[1] = make_uint2(a0.y, a1.y);
-        m[2] = make_uint2(a0.z, a1.z), m[3] = make_uint2(a0.w, a1.w);
+    auto load_groups = [&](int y, uint32_t (&m)[4]) {
+        const uint4 a0 = stream_load(grp0 + (size_t)y * w);
+        m[0] = a0.x, m[1] = a0.y, m[2] = a0.z, m[3] = a0.w;
     };
     // The four pixels of one group (HR row N of this lane's LR column), every plane.  `dr0` is row
     // N's place in the current window, `s` the ring slot of the window's first row.  Returns false
     // when some pixel is not in the window (the values are then to be replaced by fetch_global).
     // The ring is the kernel's only LDS object, so its addresses are plain byte offsets.
     typedef const float __attribute__((address_space(3))) lds_cfloat;
-    auto fetch = [&](const uint2& gm, int dr0, int s, bool checked, float4 (&a)[CH]) -> bool {
-        const int dr = __builtin_amdgcn_sbfe((int)gm.x, 15, 15) + dr0;
-        const int dc = __builtin_amdgcn_sbfe((int)gm.x, 0, 15) + dc_lane;
-        const int w1 = (int)gm.y;
+    auto fetch = [&](const uint32_t gm, int dr0, int s, bool checked, float4 (&a)[CH]) -> bool {
+        const int dr = grp_dr(gm) + dr0;
+        const int dc = grp_dc(gm) + dc_lane;
         // sources in other rows than the first pixel's are rare: one branch for the whole wave
-        const bool rows_differ = __builtin_amdgcn_ballot_w64((w1 & 0x3E0F83E0) != 0) != 0;
+        const bool rows_differ = __builtin_amdgcn_ballot_w64((gm & kGrpRowBits) != 0) != 0;
         unsigned far_row = (unsigned)dr, far_col = (unsigned)dc; // unsigned maxima: negatives count as huge
         float v[4][CH];
         auto pixel = [&](int j, unsigned row_at, unsigned e) {
@@ -1056,7 +1057,7 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
 #pragma unroll
             for (int j = 1; j < 4; ++j)
             {
-                unsigned e = (unsigned)(dc + j + __builtin_amdgcn_sbfe(w1, 10 * (j - 1), 5));
+                unsigned e = (unsigned)(dc + j + grp_dx(gm, j));
                 if (checked)
                     far_col = max(far_col, e);
                 if (j == 1)
@@ -1073,8 +1074,8 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
 #pragma unroll
             for (int j = 1; j < 4; ++j)
             {
-                const int drj = dr + __builtin_amdgcn_sbfe(w1, 10 * (j - 1) + 5, 5);
-                unsigned e = (unsigned)(dc + j + __builtin_amdgcn_sbfe(w1, 10 * (j - 1), 5));
+                const int drj = dr + grp_dy(gm, j);
+                unsigned e = (unsigned)(dc + j + grp_dx(gm, j));
                 if (checked)
                     far_row = max(far_row, (unsigned)drj), far_col = max(far_col, e);
                 unsigned row_at = row_offset(drj);
@@ -1089,11 +1090,11 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
         for (int c = 0; c < CH; ++c)
             a[c] = make_float4(v[0][c], v[1][c], v[2][c], v[3][c]);
         return !checked ||
-               ((gm.x & kGrpFar) == 0 && far_row < (unsigned)kFwdSpan && far_col < (unsigned)(4 * kFwdQuads));
+               ((gm & kGrpFar) == 0 && far_row < (unsigned)kFwdSpan && far_col < (unsigned)(4 * kFwdQuads));
     };
-    auto fetch_global = [&](const uint2& gm, int N, float4 (&a)[CH]) {
+    auto fetch_global = [&](const uint32_t gm, int N, float4 (&a)[CH]) {
         int col[4], row[4];
-        if (gm.x & kGrpFar)
+        if (gm & kGrpFar)
         {
             const short2* m = (const short2*)raw_bwd.p[k] + (size_t)reflect101(N, H) * W + 4 * xl;
 #pragma unroll
@@ -1102,14 +1103,13 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
         }
         else
         {
-            const int w1 = (int)gm.y;
-            col[0] = 4 * xl + __builtin_amdgcn_sbfe((int)gm.x, 0, 15);
-            row[0] = N + __builtin_amdgcn_sbfe((int)gm.x, 15, 15);
+            col[0] = 4 * xl + grp_dc(gm);
+            row[0] = N + grp_dr(gm);
 #pragma unroll
             for (int j = 1; j < 4; ++j)
             {
-                col[j] = col[0] + j + __builtin_amdgcn_sbfe(w1, 10 * (j - 1), 5);
-                row[j] = row[0] + __builtin_amdgcn_sbfe(w1, 10 * (j - 1) + 5, 5);
+                col[j] = col[0] + j + grp_dx(gm, j);
+                row[j] = row[0] + grp_dy(gm, j);
             }
         }
         float v[4][CH];
@@ -1128,14 +1128,14 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
     };
     // All four groups of an LR row from global memory: one unaligned 16-byte gather per group and plane
     // where the group is a run of pixels inside the image, pixel by pixel otherwise.
-    auto fetch_global_rows = [&](const uint2 (&gm)[4], int N0, float4 (&a)[4][CH]) {
+    auto fetch_global_rows = [&](const uint32_t (&gm)[4], int N0, float4 (&a)[4][CH]) {
         bool run[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
         {
-            const int col0 = 4 * xl + __builtin_amdgcn_sbfe((int)gm[r].x, 0, 15);
-            const int row0 = N0 + r + __builtin_amdgcn_sbfe((int)gm[r].x, 15, 15);
-            run[r] = gm[r].y == 0 && (gm[r].x & kGrpFar) == 0 && (unsigned)row0 < (unsigned)H && col0 >= 0 && col0 + 3 < W;
+            const int col0 = 4 * xl + grp_dc(gm[r]);
+            const int row0 = N0 + r + grp_dr(gm[r]);
+            run[r] = (gm[r] & (kGrpOtherBits | kGrpFar)) == 0 && (unsigned)row0 < (unsigned)H && col0 >= 0 && col0 + 3 < W;
             const size_t idx = run[r] ? (size_t)row0 * W + col0 : (size_t)H * W;
 #pragma unroll
             for (int c = 0; c < CH; ++c)
@@ -1168,8 +1168,8 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
 
     float rr[5][CH];
     const int ya = max(y0 - 1, 0);
-    const uint2 m0 = make_uint2(((const uint32_t*)(grp0 + (size_t)ya * w))[3], ((const uint32_t*)(grp1 + (size_t)ya * w))[3]);
-    uint2 mc[4];
+    const uint32_t m0 = ((const uint32_t*)(grp0 + (size_t)ya * w))[3];
+    uint32_t mc[4];
     load_groups(y0, mc);
     __syncthreads();
     {
@@ -1210,7 +1210,7 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
         const uint8_t place_next = (uint8_t)__builtin_amdgcn_readlane((int)kinds, ahead & 63);
         float4 sv[kSlots];
         batch_load(more ? 4 * y + 3 + kFwdMy : H, sv);
-        uint2 mn[4];
+        uint32_t mn[4];
         load_groups(min(y + 1, h - 1), mn);
         const packed_floats<CH> yn = *(const packed_floats<CH>*)(yk + (size_t)min(y + 1, h - 1) * w * CH);
 
@@ -2042,7 +2042,7 @@ static int launch_group_maps(const int16_t* bwd_map, uint32_t* dec_bwd, size_t h
         return rc;
     const int hr_rows = (int)(hr_px / hr_cols), w = hr_cols / 4, h = hr_rows / 4;
     const int strips_x = (w + kFwdStrip - 1) / kFwdStrip;
-    hipLaunchKernelGGL(k_group_flags, dim3(strips_x, h), dim3(64), 0, st, dec_bwd, (uint8_t*)(dec_bwd + hr_px / 2),
+    hipLaunchKernelGGL(k_group_flags, dim3(strips_x, h), dim3(64), 0, st, dec_bwd, (uint8_t*)(dec_bwd + hr_px / 4),
                        hr_rows, hr_cols, strips_x);
     return check_launch("group_flags");
 }
