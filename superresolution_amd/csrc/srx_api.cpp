@@ -95,6 +95,7 @@ struct srx_handle
 
     // rings (lib/include/super_resolution.hpp:182-190)
     std::vector<DeviceBuffer> frames, motions, results;
+    std::vector<DeviceBuffer> frames8; // the 8-bit originals of `frames`, kept when the source delivers 8-bit frames
     int storePos = -1, procPos = -1, outPos = -1;
     int radius = 0; // temporalAreaRadius latched at initImpl (ring sizes are fixed there)
     int rows = 0, cols = 0, ch = 0, depth = SRX_8U;
@@ -104,7 +105,7 @@ struct srx_handle
     DeviceBuffer prev_dev;
     srx_image prev_hdr{};
     DeviceBuffer staging, flow_dev, flow_planes, batch_out;
-    std::vector<DeviceBuffer> batch_frames, batch_motions;
+    std::vector<DeviceBuffer> batch_frames, batch_motions, batch_frames8;
     PinnedBuffer dst_host;
     int outputMemory = SRX_MEM_HOST;
 
@@ -171,7 +172,7 @@ struct srx_handle
         return SRX_OK;
     }
 
-    int to_float(const srx_image& im, float* dst);
+    int to_float(const srx_image& im, float* dst, DeviceBuffer* keep_bytes = nullptr);
     int add_new_frame(const srx_image& frame, bool flow_ready = false);
     int read_ahead();
     int process_frame(int idx);
@@ -181,18 +182,20 @@ struct srx_handle
 };
 
 // frame.convertTo(at(storePos, frames), CV_32F): lib/src/btv_l1.cpp:519
-int srx_handle::to_float(const srx_image& im, float* dst)
+// keep_bytes: where an 8-bit frame's bytes stay on the device (the forward kernel reads them in place of the floats)
+int srx_handle::to_float(const srx_image& im, float* dst, DeviceBuffer* keep_bytes)
 {
     const size_t count = (size_t)im.rows * im.cols * im.channels;
     if (im.depth == SRX_32F)
         return copy_to_device(im, dst, stream);
-    if (int rc = staging.reserve(count * elem_size(im.depth)))
+    DeviceBuffer& raw = im.depth == SRX_8U && keep_bytes ? *keep_bytes : staging;
+    if (int rc = raw.reserve(count * elem_size(im.depth)))
         return rc;
-    if (int rc = copy_to_device(im, staging.get(), stream))
+    if (int rc = copy_to_device(im, raw.get(), stream))
         return rc;
     if (im.depth == SRX_16U)
-        return launch_convert_16u_to_32f(staging.as<uint16_t>(), count, dst, stream);
-    return launch_convert_8u_to_32f(staging.as<uint8_t>(), count, dst, stream);
+        return launch_convert_16u_to_32f(raw.as<uint16_t>(), count, dst, stream);
+    return launch_convert_8u_to_32f(raw.as<uint8_t>(), count, dst, stream);
 }
 
 // opticalFlow->calc(frame0, frame1, flow): lib/src/btv_l1.cpp:315,522
@@ -291,7 +294,7 @@ int srx_handle::add_new_frame(const srx_image& frame, bool flow_ready)
         DeviceBuffer& f = frames[slot(storePos)];
         if (int rc = f.reserve(px * ch * sizeof(float)))
             return rc;
-        if (int rc = to_float(frame, f.as<float>()))
+        if (int rc = to_float(frame, f.as<float>(), &frames8[slot(storePos)]))
             return rc;
     }
     if (storePos > 0 && flow_ready)
@@ -409,13 +412,17 @@ int srx_handle::process_frame(int idx)
         return SRX_OK;
     const float* y[kMaxWindow];
     const float* fm[kMaxWindow];
+    const uint8_t* y8[kMaxWindow];
     const int K = end - start + 1;
     for (int i = start, k = 0; i <= end; ++i, ++k)
     {
         y[k] = frames[slot(i)].as<float>();
+        y8[k] = frames8[slot(i)].as<uint8_t>();
         if (i < end)
             fm[k] = motions[slot(i)].as<float>();
     }
+    if (depth == SRX_8U)
+        solver.byte_frames(y8, K);
     if (int rc = solver.process(y, fm, K, base, rows, cols, ch, p, nullptr, nullptr, stream))
         return rc;
     // results ring keeps the cropped frame already converted to 8 bit; the
@@ -438,6 +445,8 @@ int srx_handle::init_impl()
     results.clear();
     motions.clear();
     frames.resize(cache);
+    frames8.clear();
+    frames8.resize(cache);
     results.resize(cache);
     motions.resize(cache);
     storePos = -1;
@@ -946,16 +955,19 @@ SRX_API int srx_process(srx_handle* h, const srx_image* frames, int n, const srx
     {
         h->batch_frames.resize(n);
         h->batch_motions.resize(n);
+        h->batch_frames8.resize(n);
     }
     const float* y[kMaxWindow];
     const float* m[kMaxWindow];
+    const uint8_t* y8[kMaxWindow];
     for (int i = 0; i < n && !dry; ++i)
     {
         if (int rc = h->batch_frames[i].reserve(px * ch * sizeof(float)))
             return rc;
-        if (int rc = h->to_float(frames[i], h->batch_frames[i].as<float>()))
+        if (int rc = h->to_float(frames[i], h->batch_frames[i].as<float>(), &h->batch_frames8[i]))
             return rc;
         y[i] = h->batch_frames[i].as<float>();
+        y8[i] = h->batch_frames8[i].as<uint8_t>();
     }
     const int B = h->p.btvKernelSize, s = h->p.scale;
     const int orows = rows * s - 2 * B, ocols = cols * s - 2 * B;
@@ -989,6 +1001,8 @@ SRX_API int srx_process(srx_handle* h, const srx_image* frames, int n, const srx
         }
         if (dry)
             return SRX_OK;
+        if (f0.depth == SRX_8U)
+            h->solver.byte_frames(y8, n);
         rc = h->solver.process(y, m, n, base_idx, rows, cols, ch, h->p, nullptr, nullptr, h->stream);
     }
     else
@@ -1012,6 +1026,8 @@ SRX_API int srx_process(srx_handle* h, const srx_image* frames, int n, const srx
         }
         if (dry)
             return SRX_OK;
+        if (f0.depth == SRX_8U)
+            h->solver.byte_frames(y8, n);
         rc = h->solver.run(y, m, n, base_idx, rows, cols, ch, h->p, nullptr, nullptr, h->stream);
     }
     if (rc)
@@ -1148,6 +1164,7 @@ SRX_API int srx_collect_garbage(srx_handle* h)
     h->flow_dev.release();
     h->batch_out.release();
     h->batch_frames.clear();
+    h->batch_frames8.clear();
     h->batch_motions.clear();
     return SRX_OK;
 }

@@ -125,6 +125,19 @@ class Solver
             const Params& p, float* out, float* x_full, hipStream_t st);
     int process(const float* const* y, const float* const* fwd_motions, int K, int base_idx, int rows, int cols,
                 int ch, const Params& p, float* out, float* x_full, hipStream_t st);
+    // The 8-bit originals of the K frames of the next run()/process() call (device, rows x cols x ch bytes each,
+    // dense): when the frames came in as 8-bit images the float copies passed to run() hold the same values, and
+    // the specialised forward kernel reads the bytes instead (a quarter of the traffic).  Valid for one call.
+    void byte_frames(const uint8_t* const* y8, int K)
+    {
+        y8_count_ = 0;
+        if (y8 && K >= 1 && K <= kMaxWindow)
+        {
+            for (int k = 0; k < K; ++k)
+                y8_[k] = y8[k];
+            y8_count_ = K;
+        }
+    }
     // HR image after the last run (device), rows*scale x cols*scale x ch; planar with this plane
     // stride when last_x_plane_stride() != 0, interleaved otherwise
     const float* last_x() const { return x_[cur_].as<float>(); }
@@ -147,6 +160,8 @@ class Solver
     int ensure(int K, int rows, int cols, int ch, int scale, hipStream_t st);
     std::vector<DeviceBuffer> fwd_maps_, bwd_maps_, dec_fwd_, dec_bwd_, signs_, rel_;
     DeviceBuffer x_[2];
+    const uint8_t* y8_[kMaxWindow] = {};
+    int y8_count_ = 0;
     int cur_ = 0;
     size_t ps_ = 0; // plane stride of x_ (0: interleaved)
     CubicTablesDev tables_;

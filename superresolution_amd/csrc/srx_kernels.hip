@@ -44,6 +44,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 // Diagnostic builds only (-DSRX_STAMPS): every wave of the update kernel records s_memtime at its phase
 // boundaries into a device array that srx_debug_stamps copies out.  No stamp exists in the product build.
@@ -879,7 +880,8 @@ inline size_t forward_lds_bytes(int ch)
     return (size_t)kFwdRing * ch * kFwdRowBytes;
 }
 
-template <int CH>
+// Y8: the LR frames are the 8-bit originals (a quarter of the bytes of their float copies; the values are the same)
+template <int CH, bool Y8>
 __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sign_lds(
     const float* __restrict__ X, int H, int W, size_t ps, PtrList raw_bwd, PtrList grp_bwd, PtrList ys, MutPtrList signs,
     int K, GaussK g, int strips_x, int rows_per_tile, unsigned n_tiles)
@@ -924,7 +926,12 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
     const uint4* grp0 = (const uint4*)grp_bwd.p[k] + xl;
     // per LR row: 1 = every gather of this strip's row stays inside the window (k_group_flags)
     const uint8_t* flags = (const uint8_t*)((const uint32_t*)grp_bwd.p[k] + (size_t)H * W / 4) + strip;
-    const float* yk = (const float*)ys.p[k] + (size_t)xl * CH;
+    typedef typename std::conditional<Y8, uint8_t, float>::type y_elem;
+    struct __attribute__((packed)) y_pack
+    {
+        y_elem v[CH];
+    };
+    const y_elem* yk = (const y_elem*)ys.p[k] + (size_t)xl * CH;
     uint32_t* sp = (uint32_t*)signs.p[k] + 2 * (size_t)xl;
     const float k0 = g.k[2], k1 = g.k[3], k2 = g.k[4];
 
@@ -1187,7 +1194,7 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
     // register sets was tried and is slower: with loads under branches in the loop the compiler's wait counts
     // at the joins fall back to "all loads done", which puts the whole memory latency in front of every row.)
     int s = 0; // ring slot of the first row of the current LR row's window
-    packed_floats<CH> yv = *(const packed_floats<CH>*)(yk + (size_t)y0 * w * CH);
+    y_pack yv = *(const y_pack*)(yk + (size_t)y0 * w * CH);
     // The kinds of the tile's rows, 64 rows at a time, one per lane: a load per row would put a memory
     // latency in front of every row (the kind decides the row's code path).
     uint32_t kinds = flags[(size_t)min(y0 + lane, h - 1) * strips_x];
@@ -1212,7 +1219,7 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
         batch_load(more ? 4 * y + 3 + kFwdMy : H, sv);
         uint32_t mn[4];
         load_groups(min(y + 1, h - 1), mn);
-        const packed_floats<CH> yn = *(const packed_floats<CH>*)(yk + (size_t)min(y + 1, h - 1) * w * CH);
+        const y_pack yn = *(const y_pack*)(yk + (size_t)min(y + 1, h - 1) * w * CH);
 
         if (place == kRowIdentity)
         {
@@ -1271,7 +1278,7 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
             float sum = rr[2][c] * k0;
             sum += (rr[1][c] + rr[3][c]) * k1;
             sum += (rr[0][c] + rr[4][c]) * k2;
-            sg |= (uint32_t)((int)dsign(yv.v[c], sum) + 1) << (10 * c);
+            sg |= (uint32_t)((int)dsign((float)yv.v[c], sum) + 1) << (10 * c);
         }
         // Cell (y-1) = {S(y-1), S(y)} leaves as one 8-byte store once both rows are known (whole cache
         // lines per wave); only the cells at the tile's first and last row are written in halves, the other
@@ -2149,7 +2156,7 @@ bool forward_fast_eligible(int hr_rows, int hr_cols, int ch, int scale, const Ga
 
 int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const PtrList& raw_bwd,
                         const PtrList* dec_bwd, const PtrList& y, const MutPtrList& signs, int K, int scale,
-                        const GaussK& g, size_t generic_plane_stride, hipStream_t st)
+                        const GaussK& g, size_t generic_plane_stride, hipStream_t st, const PtrList* y_bytes)
 {
     if (ch != 1 && ch != 3)
     {
@@ -2177,9 +2184,13 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, dev) != hipSuccess)
                 return check_launch("forward_sign_lds (device query)");
-            if (hipFuncSetAttribute((const void*)k_forward_sign_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute((const void*)k_forward_sign_lds<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)forward_lds_bytes(1)) != hipSuccess ||
-                hipFuncSetAttribute((const void*)k_forward_sign_lds<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                hipFuncSetAttribute((const void*)k_forward_sign_lds<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)forward_lds_bytes(3)) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_forward_sign_lds<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)forward_lds_bytes(1)) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_forward_sign_lds<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)forward_lds_bytes(3)) != hipSuccess)
                 return check_launch("forward_sign_lds (LDS size)");
             cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -2192,12 +2203,21 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
         const unsigned n_tiles = (unsigned)strips_x * row_groups;
         const dim3 gr(xcd_grid(n_tiles), passes), b(64 * waves);
         const size_t lds = forward_lds_bytes(ch);
-        if (ch == 1)
-            hipLaunchKernelGGL(k_forward_sign_lds<1>, gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd, y, signs,
-                               K, g, strips_x, rows_per_tile, n_tiles);
+        if (y_bytes)
+        {
+            if (ch == 1)
+                hipLaunchKernelGGL((k_forward_sign_lds<1, true>), gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd,
+                                   *y_bytes, signs, K, g, strips_x, rows_per_tile, n_tiles);
+            else
+                hipLaunchKernelGGL((k_forward_sign_lds<3, true>), gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd,
+                                   *y_bytes, signs, K, g, strips_x, rows_per_tile, n_tiles);
+        }
+        else if (ch == 1)
+            hipLaunchKernelGGL((k_forward_sign_lds<1, false>), gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd, y,
+                               signs, K, g, strips_x, rows_per_tile, n_tiles);
         else
-            hipLaunchKernelGGL(k_forward_sign_lds<3>, gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd, y, signs,
-                               K, g, strips_x, rows_per_tile, n_tiles);
+            hipLaunchKernelGGL((k_forward_sign_lds<3, false>), gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd, y,
+                               signs, K, g, strips_x, rows_per_tile, n_tiles);
         return check_launch("forward_sign_lds");
     }
     if (g_kernel_path == 0 && scale == 2 && g.n == 5 && generic_plane_stride != 0 && hr_cols >= 8 && hr_rows >= 8 &&

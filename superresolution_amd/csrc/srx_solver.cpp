@@ -306,6 +306,8 @@ void Solver::release()
 int Solver::run(const float* const* y, const float* const* rel, int K, int base_idx, int rows, int cols, int ch,
                 const Params& p, float* out, float* x_full, hipStream_t st)
 {
+    const int announced_bytes = y8_count_; // byte_frames() holds for one call
+    y8_count_ = 0;
     if (int rc = validate_params(p))
         return rc;
     if (K < 1 || K > kMaxWindow || base_idx < 0 || base_idx >= K)
@@ -359,8 +361,10 @@ int Solver::run(const float* const* y, const float* const* rel, int K, int base_
                        (s != 4 || forward_fast_eligible((int)R, (int)C, ch, s, gauss_));
     const bool fastA = fastB && s == 4;
     ps_ = fastB ? plane_stride_for((size_t)R * C) : 0;
-    PtrList fwd{}, bwd{}, dfwd{}, dbwd{}, ys{}, sg{};
+    PtrList fwd{}, bwd{}, dfwd{}, dbwd{}, ys{}, ys8{}, sg{};
     MutPtrList sgm{};
+    // 8-bit originals of the frames, announced for this call only (byte_frames)
+    const bool have_bytes = fastA && announced_bytes == K;
     for (int k = 0; k < K; ++k)
     {
         if (int rc = launch_build_maps(rel[k], rows, cols, s, t, fwd_maps_[k].as<int16_t>(),
@@ -372,6 +376,7 @@ int Solver::run(const float* const* y, const float* const* rel, int K, int base_
         dfwd.p[k] = dec_fwd_[k].get();
         dbwd.p[k] = dec_bwd_[k].get();
         ys.p[k] = y[k];
+        ys8.p[k] = have_bytes ? y8_[k] : nullptr;
         sg.p[k] = signs_[k].get();
         sgm.p[k] = signs_[k].get();
     }
@@ -401,7 +406,7 @@ int Solver::run(const float* const* y, const float* const* rel, int K, int base_
         if (time_it)
             SRX_HIP(hipEventRecord(events_[3 * timed], st));
         if (int rc = launch_forward_sign(x_[cur_].as<float>(), (int)R, (int)C, ch, bwd, fastA ? &dbwd : nullptr, ys,
-                                         sgm, K, s, gauss_, ps_, st))
+                                         sgm, K, s, gauss_, ps_, st, have_bytes ? &ys8 : nullptr))
             return rc;
         if (time_it)
             SRX_HIP(hipEventRecord(events_[3 * timed + 1], st));
@@ -439,6 +444,17 @@ int Solver::run(const float* const* y, const float* const* rel, int K, int base_
 int Solver::process(const float* const* y, const float* const* fwd_motions, int K, int base_idx, int rows, int cols,
                     int ch, const Params& p, float* out, float* x_full, hipStream_t st)
 {
+    // announced byte frames are for this call only, also when it fails before it gets to run()
+    struct Forget
+    {
+        int& count;
+        bool armed = true;
+        ~Forget()
+        {
+            if (armed)
+                count = 0;
+        }
+    } forget{y8_count_};
     if (K < 1 || K > kMaxWindow || base_idx < 0 || base_idx >= K)
     {
         set_error("process: window size or base index out of range");
@@ -460,6 +476,7 @@ int Solver::process(const float* const* y, const float* const* fwd_motions, int 
     }
     if (int rc = launch_relative_motions(f, r, K, base_idx, (size_t)rows * cols * 2, st))
         return rc;
+    forget.armed = false;
     return run(y, relp, K, base_idx, rows, cols, ch, p, out, x_full, st);
 }
 
