@@ -59,11 +59,11 @@ int hip_fail(hipError_t e, const char* what);
 int launch_relative_motions(const PtrList& fwd, const MutPtrList& rel, int n, int base_idx, size_t count,
                             hipStream_t st);
 // dec_fwd / dec_bwd (optional, scale 4 only): decoded maps for the specialised kernels;
-// dec_bwd holds dec_bwd_words(hr pixels) words: the group map (one word per four pixels) and
+// dec_bwd holds dec_bwd_words(hr pixels) words: the group map in its short and its long form (one and two words per four pixels) and
 // behind it one flag byte per LR row and strip of the forward kernel (fewer than hr_px / 16)
 inline size_t dec_bwd_words(size_t hr_px)
 {
-    return hr_px / 4 + hr_px / 64 + 4;
+    return 3 * (hr_px / 4) + hr_px / 64 + 4;
 }
 int launch_build_maps(const float* rel, int rows, int cols, int scale, const CubicTables& t, int16_t* fwd_map,
                       int16_t* bwd_map, uint32_t* dec_fwd, uint32_t* dec_bwd, hipStream_t st);

@@ -100,22 +100,46 @@ namespace
 //                left and top edges, which therefore need no entries of their
 //                own); 25 = all weights 0 (target outside the image, or in the
 //                last column / row, whose only tap is a reflected one)
-// group map entry of the backward map: one word for the sources (col_i, row_i), i = 0..3, of 4 neighbouring
-// pixels of HR row N = 4y-1+r (the map row itself is the reflected one at the top edge), columns 4x..4x+3:
-//   bits 0..8   col_0 - 4x, bits 9..17 row_0 - N, both signed (-256 .. 255);
-//   for i = 1..3, at bit 18 + 4(i-1): col_i - (col_0 + i) (2 bits, signed: -2 .. 1), then row_i - row_0
-//               (2 bits, signed); all zero when the four sources are one run of pixels;
-//   bit 30      "far" - some coordinate does not fit its field (read the raw map instead)
-// Four entries (r = 0..3) per LR pixel, 16 bytes: half of what the raw map takes for the same 16 pixels.
+// Group map of the backward map, two forms.  An entry describes the sources (col_i, row_i), i = 0..3, of 4
+// neighbouring pixels of HR row N = 4y-1+r (the map row itself is the reflected one at the top edge), columns
+// 4x..4x+3; four entries (r = 0..3) per LR pixel.
+//  short form, one word (16 bytes per LR pixel, half of what the raw map takes for the same 16 pixels):
+//   bits 0..6   col_0 - 4x, bits 7..13 row_0 - N, both signed (-63 .. 63);
+//   for i = 1..3, at bit 14 + 6(i-1): col_i - (col_0 + i), then row_i - row_0 (3 bits each, signed: -4 .. 3);
+//               all zero when the four sources are one run of pixels;
+//   the value kGrpFar (a row field of -64, nothing else): some coordinate does not fit its field.
+//  long form, two words in two planes:
+//   word 0  bits 0..14 col_0 - 4x, bits 15..29 row_0 - N, both signed;
+//           bit 30: "far" - some coordinate does not fit its field (read the raw map instead)
+//   word 1  for i = 1..3, at bit 10(i-1): col_i - (col_0 + i) (5 bits, signed), then row_i - row_0
+//           (5 bits, signed); all zero when the four sources are one run of pixels
+// The forward kernel reads the short form for LR rows in which every lane's sources lie in its LDS window (nearly
+// all rows: half the map traffic) and the long form for the others, where lanes go different ways.
 // Sources outside the image keep their coordinates: the forward kernel stages zeros around the image.
-constexpr uint32_t kGrpFar = 1u << 30;
-constexpr uint32_t kGrpRowBits = 0x33300000u;   // the three row_i - row_0 fields
-constexpr uint32_t kGrpOtherBits = 0x3FFC0000u; // all fields of pixels 1..3
-__device__ __forceinline__ int grp_dc(uint32_t g) { return __builtin_amdgcn_sbfe((int)g, 0, 9); }
-__device__ __forceinline__ int grp_dr(uint32_t g) { return __builtin_amdgcn_sbfe((int)g, 9, 9); }
-__device__ __forceinline__ int grp_dx(uint32_t g, int j) { return __builtin_amdgcn_sbfe((int)g, 18 + 4 * (j - 1), 2); }
-__device__ __forceinline__ int grp_dy(uint32_t g, int j) { return __builtin_amdgcn_sbfe((int)g, 20 + 4 * (j - 1), 2); }
-constexpr int kGrpMaxDim = 16383; // displacements must fit 15 signed bits
+constexpr uint32_t kGrpFar = 0x40u << 7;        // short form
+constexpr uint32_t kGrpLongFar = 1u << 30;      // long form, word 0
+constexpr int kGrpMaxDim = 16383;               // long form: displacements must fit 15 signed bits
+template <bool LONG> struct Grp
+{
+    static __device__ __forceinline__ bool far(uint2 g) { return LONG ? (g.x & kGrpLongFar) != 0 : g.x == kGrpFar; }
+    static __device__ __forceinline__ int dc(uint2 g) { return __builtin_amdgcn_sbfe((int)g.x, 0, LONG ? 15 : 7); }
+    static __device__ __forceinline__ int dr(uint2 g) { return __builtin_amdgcn_sbfe((int)g.x, LONG ? 15 : 7, LONG ? 15 : 7); }
+    static __device__ __forceinline__ int dx(uint2 g, int j)
+    {
+        return LONG ? __builtin_amdgcn_sbfe((int)g.y, 10 * (j - 1), 5) : __builtin_amdgcn_sbfe((int)g.x, 14 + 6 * (j - 1), 3);
+    }
+    static __device__ __forceinline__ int dy(uint2 g, int j)
+    {
+        return LONG ? __builtin_amdgcn_sbfe((int)g.y, 10 * (j - 1) + 5, 5) : __builtin_amdgcn_sbfe((int)g.x, 17 + 6 * (j - 1), 3);
+    }
+    // some source lies in another row than the first pixel's
+    static __device__ __forceinline__ bool rows_differ(uint2 g)
+    {
+        return LONG ? (g.y & 0x3E0F83E0u) != 0 : (g.x & ((7u << 17) | (7u << 23) | (7u << 29))) != 0;
+    }
+    // the four sources are one run of pixels
+    static __device__ __forceinline__ bool run(uint2 g) { return LONG ? g.y == 0 : (g.x & 0xFFFFC000u) == 0; }
+};
 constexpr uint32_t kFwdCellMask = 0x00FFFFFFu;
 constexpr int kFwdLutShift = 24;
 constexpr uint32_t kFwdLutZero = 25;
@@ -313,24 +337,43 @@ __global__ void k_group_maps(const short2* __restrict__ bwd_map, uint32_t* __res
     const int N = 4 * y - 1 + r;
     const short2* m = bwd_map + (size_t)reflect101(N, H) * W + 4 * x;
     const int col0 = m[0].x, row0 = m[0].y;
-    const int ddx = clampi(col0 - 4 * x, -256, 255), ddy = clampi(row0 - N, -256, 255);
-    bool far = ddx != col0 - 4 * x || ddy != row0 - N;
-    uint32_t others = 0;
-    for (int i = 1; i <= 3; ++i)
     {
-        const int dx = m[i].x - (col0 + i), dy = m[i].y - row0;
-        far = far || dx < -2 || dx > 1 || dy < -2 || dy > 1;
-        others |= ((uint32_t)(dx & 3) | ((uint32_t)(dy & 3) << 2)) << (4 * (i - 1));
+        const int ddx = clampi(col0 - 4 * x, -63, 63), ddy = clampi(row0 - N, -63, 63);
+        bool far = ddx != col0 - 4 * x || ddy != row0 - N;
+        uint32_t others = 0;
+        for (int i = 1; i <= 3; ++i)
+        {
+            const int dx = m[i].x - (col0 + i), dy = m[i].y - row0;
+            far = far || dx < -4 || dx > 3 || dy < -4 || dy > 3;
+            others |= ((uint32_t)(dx & 7) | ((uint32_t)(dy & 7) << 3)) << (6 * (i - 1));
+        }
+        grp[e] = far ? kGrpFar : (((uint32_t)ddx & 0x7Fu) | (((uint32_t)ddy & 0x7Fu) << 7) | (others << 14));
     }
-    grp[e] = ((uint32_t)ddx & 0x1FFu) | (((uint32_t)ddy & 0x1FFu) << 9) | (others << 18) | (far ? kGrpFar : 0u);
+    {
+        const int ddx = clampi(col0 - 4 * x, -16384, 16383), ddy = clampi(row0 - N, -16384, 16383);
+        bool far = ddx != col0 - 4 * x || ddy != row0 - N;
+        uint32_t w1 = 0;
+        for (int i = 1; i <= 3; ++i)
+        {
+            const int dx = m[i].x - (col0 + i), dy = m[i].y - row0;
+            far = far || dx < -16 || dx > 15 || dy < -16 || dy > 15;
+            w1 |= ((uint32_t)(dx & 31) | ((uint32_t)(dy & 31) << 5)) << (10 * (i - 1));
+        }
+        grp[entries + e] = ((uint32_t)ddx & 0x7FFFu) | (((uint32_t)ddy & 0x7FFFu) << 15) | (far ? kGrpLongFar : 0u);
+        grp[2 * entries + e] = w1;
+    }
 }
 
 // Geometry of the forward kernel's LDS window (described above k_forward_sign_lds)
 constexpr int kFwdStrip = 63;
 // 47 rows of three planes fill the CU's 160 KB: motions of up to 19 HR rows either way stay in the window
 // (with 40 rows / 15, windows of the benchmark clip whose corners move by 16 to 21 rows cost 15 % more)
-constexpr int kFwdRing = 47;
-constexpr int kFwdMy = 19;
+#ifndef SRX_FWD_RING
+#define SRX_FWD_RING 47
+#define SRX_FWD_MY 19
+#endif
+constexpr int kFwdRing = SRX_FWD_RING;
+constexpr int kFwdMy = SRX_FWD_MY;
 constexpr int kFwdMx = 16;
 constexpr int kFwdQuads = kFwdStrip + 1 + kFwdMx / 2; // 16-byte groups per staged row
 constexpr int kFwdRowBytes = 16 * kFwdQuads;          // one row of one plane
@@ -342,42 +385,53 @@ static_assert(kFwdMx % 4 == 0, "staged columns start at a multiple of four");
 
 // One flag byte per (LR row, strip) of a frame's group map: kRowInside when every pixel the forward
 // kernel gathers for that row of that strip lies inside its LDS window and no group is "far", so that
-// the kernel may skip the checks; kRowOutside when (nearly) no lane finds its pixels there, so that
-// the kernel goes to global memory right away; kRowIdentity when every group of the row maps its four
+// the kernel may skip the checks; kRowOutside when a quarter of the lanes or more do not find their pixels
+// there, so that the kernel goes to global memory right away (kRowMixed: a few lanes do not, e.g. those with
+// a "far" group at a motion boundary - they alone go to global memory; these two kinds of rows are read in the
+// long form of the entries, the others in the short form); kRowIdentity when every group of the row maps its four
 // pixels onto themselves (zero motion: the base frame of a window, a static scene), so that the kernel
 // needs no entry at all.  One wave per (strip, LR row); lanes as in the forward kernel.
 constexpr uint8_t kRowMixed = 0, kRowInside = 1, kRowOutside = 2, kRowIdentity = 3;
 __global__ void k_group_flags(const uint32_t* __restrict__ grp, uint8_t* __restrict__ flags, int H, int W, int strips_x)
 {
-    const int w = W >> 2;
+    const int w = W >> 2, h = H >> 2;
     const int strip = blockIdx.x, y = blockIdx.y, lane = threadIdx.x;
     const int x0 = strip * kFwdStrip;
     const int xl = min(max(x0 - 1 + lane, 0), w - 1);
     const int dc_lane = 4 * xl - (4 * (x0 - 1) - kFwdMx);
+    const size_t entries = (size_t)h * w * 4;
+    // ok: every group of the lane lies in the window by its short entry (then the long one says the same);
+    // any: some group does by its long entry
     bool ok = true, any = false, same = true;
     for (int r = 0; r < 4; ++r)
     {
         const size_t e = ((size_t)y * w + xl) * 4 + r;
-        const uint32_t w0 = grp[e];
-        same = same && w0 == 0u;
-        const int dr = grp_dr(w0) + kFwdMy + 1 + r;
-        const int dc = grp_dc(w0) + dc_lane;
-        bool in = (w0 & kGrpFar) == 0 && (unsigned)dr < (unsigned)kFwdSpan && (unsigned)dc < (unsigned)(4 * kFwdQuads);
-        for (int j = 1; j < 4; ++j)
+        const uint2 gs = make_uint2(grp[e], 0u), gl = make_uint2(grp[entries + e], grp[2 * entries + e]);
+        same = same && gs.x == 0u;
+        bool in_s, in_l;
         {
-            const int drj = dr + grp_dy(w0, j);
-            const int e_ = dc + j + grp_dx(w0, j);
-            in = in && (unsigned)drj < (unsigned)kFwdSpan && (unsigned)e_ < (unsigned)(4 * kFwdQuads);
+            const int dr = Grp<false>::dr(gs) + kFwdMy + 1 + r, dc = Grp<false>::dc(gs) + dc_lane;
+            in_s = !Grp<false>::far(gs) && (unsigned)dr < (unsigned)kFwdSpan && (unsigned)dc < (unsigned)(4 * kFwdQuads);
+            for (int j = 1; j < 4; ++j)
+                in_s = in_s && (unsigned)(dr + Grp<false>::dy(gs, j)) < (unsigned)kFwdSpan &&
+                       (unsigned)(dc + j + Grp<false>::dx(gs, j)) < (unsigned)(4 * kFwdQuads);
         }
-        ok = ok && in;
-        any = any || in;
+        {
+            const int dr = Grp<true>::dr(gl) + kFwdMy + 1 + r, dc = Grp<true>::dc(gl) + dc_lane;
+            in_l = !Grp<true>::far(gl) && (unsigned)dr < (unsigned)kFwdSpan && (unsigned)dc < (unsigned)(4 * kFwdQuads);
+            for (int j = 1; j < 4; ++j)
+                in_l = in_l && (unsigned)(dr + Grp<true>::dy(gl, j)) < (unsigned)kFwdSpan &&
+                       (unsigned)(dc + j + Grp<true>::dx(gl, j)) < (unsigned)(4 * kFwdQuads);
+        }
+        ok = ok && in_s;
+        any = any || in_l;
     }
     const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
     const bool all_same = all_ok && __builtin_amdgcn_ballot_w64(!same) == 0;
     const int n_in = __builtin_popcountll(__builtin_amdgcn_ballot_w64(any));
     if (lane == 0)
         flags[(size_t)y * strips_x + strip] =
-            all_same ? kRowIdentity : (all_ok ? kRowInside : (n_in < 16 ? kRowOutside : kRowMixed));
+            all_same ? kRowIdentity : (all_ok ? kRowInside : (n_in < 48 ? kRowOutside : kRowMixed));
 }
 
 // ps == 0: interleaved destination; otherwise planar with plane stride ps
@@ -923,9 +977,11 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
     const int rbase = 4 * y0 - 2 - kFwdMy; // HR row in ring slot 0
     const int dc_lane = 4 * xl - c0;
 
-    const uint4* grp0 = (const uint4*)grp_bwd.p[k] + xl;
+    // short entries, long entries word 0 and word 1: three planes of h*w 16-byte records
+    const uint4* grp_base = (const uint4*)grp_bwd.p[k];
+    const uint4* grp0 = grp_base + xl;
     // per LR row: 1 = every gather of this strip's row stays inside the window (k_group_flags)
-    const uint8_t* flags = (const uint8_t*)((const uint32_t*)grp_bwd.p[k] + (size_t)H * W / 4) + strip;
+    const uint8_t* flags = (const uint8_t*)((const uint32_t*)grp_bwd.p[k] + 3 * ((size_t)H * W / 4)) + strip;
     typedef typename std::conditional<Y8, uint8_t, float>::type y_elem;
     struct __attribute__((packed)) y_pack
     {
@@ -1026,20 +1082,29 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
             }
     };
 
-    auto load_groups = [&](int y, uint32_t (&m)[4]) {
-        const uint4 a0 = stream_load(grp0 + (size_t)y * w);
-        m[0] = a0.x, m[1] = a0.y, m[2] = a0.z, m[3] = a0.w;
+    // The entries of LR row y: the long form for a row of kind mixed or outside, else the short form.
+    const size_t grp_plane = (size_t)h * w;
+    auto load_groups = [&](int y, uint8_t kind, uint2 (&m)[4]) {
+        const bool lng = kind == kRowMixed || kind == kRowOutside;
+        const uint4* p0 = grp0 + (size_t)y * w + (lng ? grp_plane : 0);
+        const uint4 a0 = stream_load(p0);
+        uint4 a1 = make_uint4(0u, 0u, 0u, 0u);
+        if (lng) // the same for all lanes, and rare
+            a1 = stream_load(p0 + grp_plane);
+        m[0] = make_uint2(a0.x, a1.x), m[1] = make_uint2(a0.y, a1.y);
+        m[2] = make_uint2(a0.z, a1.z), m[3] = make_uint2(a0.w, a1.w);
     };
     // The four pixels of one group (HR row N of this lane's LR column), every plane.  `dr0` is row
     // N's place in the current window, `s` the ring slot of the window's first row.  Returns false
     // when some pixel is not in the window (the values are then to be replaced by fetch_global).
     // The ring is the kernel's only LDS object, so its addresses are plain byte offsets.
     typedef const float __attribute__((address_space(3))) lds_cfloat;
-    auto fetch = [&](const uint32_t gm, int dr0, int s, bool checked, float4 (&a)[CH]) -> bool {
-        const int dr = grp_dr(gm) + dr0;
-        const int dc = grp_dc(gm) + dc_lane;
+    auto fetch = [&](auto form, const uint2 gm, int dr0, int s, bool checked, float4 (&a)[CH]) -> bool {
+        typedef Grp<decltype(form)::value> G;
+        const int dr = G::dr(gm) + dr0;
+        const int dc = G::dc(gm) + dc_lane;
         // sources in other rows than the first pixel's are rare: one branch for the whole wave
-        const bool rows_differ = __builtin_amdgcn_ballot_w64((gm & kGrpRowBits) != 0) != 0;
+        const bool rows_differ = __builtin_amdgcn_ballot_w64(G::rows_differ(gm)) != 0;
         unsigned far_row = (unsigned)dr, far_col = (unsigned)dc; // unsigned maxima: negatives count as huge
         float v[4][CH];
         auto pixel = [&](int j, unsigned row_at, unsigned e) {
@@ -1064,7 +1129,7 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
 #pragma unroll
             for (int j = 1; j < 4; ++j)
             {
-                unsigned e = (unsigned)(dc + j + grp_dx(gm, j));
+                unsigned e = (unsigned)(dc + j + G::dx(gm, j));
                 if (checked)
                     far_col = max(far_col, e);
                 if (j == 1)
@@ -1081,8 +1146,8 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
 #pragma unroll
             for (int j = 1; j < 4; ++j)
             {
-                const int drj = dr + grp_dy(gm, j);
-                unsigned e = (unsigned)(dc + j + grp_dx(gm, j));
+                const int drj = dr + G::dy(gm, j);
+                unsigned e = (unsigned)(dc + j + G::dx(gm, j));
                 if (checked)
                     far_row = max(far_row, (unsigned)drj), far_col = max(far_col, e);
                 unsigned row_at = row_offset(drj);
@@ -1097,11 +1162,13 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
         for (int c = 0; c < CH; ++c)
             a[c] = make_float4(v[0][c], v[1][c], v[2][c], v[3][c]);
         return !checked ||
-               ((gm & kGrpFar) == 0 && far_row < (unsigned)kFwdSpan && far_col < (unsigned)(4 * kFwdQuads));
+               (!G::far(gm) && far_row < (unsigned)kFwdSpan && far_col < (unsigned)(4 * kFwdQuads));
     };
-    auto fetch_global = [&](const uint32_t gm, int N, float4 (&a)[CH]) {
+    // (long entries)
+    auto fetch_global = [&](const uint2 gm, int N, float4 (&a)[CH]) {
+        typedef Grp<true> G;
         int col[4], row[4];
-        if (gm & kGrpFar)
+        if (G::far(gm))
         {
             const short2* m = (const short2*)raw_bwd.p[k] + (size_t)reflect101(N, H) * W + 4 * xl;
 #pragma unroll
@@ -1110,13 +1177,13 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
         }
         else
         {
-            col[0] = 4 * xl + grp_dc(gm);
-            row[0] = N + grp_dr(gm);
+            col[0] = 4 * xl + G::dc(gm);
+            row[0] = N + G::dr(gm);
 #pragma unroll
             for (int j = 1; j < 4; ++j)
             {
-                col[j] = col[0] + j + grp_dx(gm, j);
-                row[j] = row[0] + grp_dy(gm, j);
+                col[j] = col[0] + j + G::dx(gm, j);
+                row[j] = row[0] + G::dy(gm, j);
             }
         }
         float v[4][CH];
@@ -1135,14 +1202,15 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
     };
     // All four groups of an LR row from global memory: one unaligned 16-byte gather per group and plane
     // where the group is a run of pixels inside the image, pixel by pixel otherwise.
-    auto fetch_global_rows = [&](const uint32_t (&gm)[4], int N0, float4 (&a)[4][CH]) {
+    auto fetch_global_rows = [&](const uint2 (&gm)[4], int N0, float4 (&a)[4][CH]) {
+        typedef Grp<true> G;
         bool run[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
         {
-            const int col0 = 4 * xl + grp_dc(gm[r]);
-            const int row0 = N0 + r + grp_dr(gm[r]);
-            run[r] = (gm[r] & (kGrpOtherBits | kGrpFar)) == 0 && (unsigned)row0 < (unsigned)H && col0 >= 0 && col0 + 3 < W;
+            const int col0 = 4 * xl + G::dc(gm[r]);
+            const int row0 = N0 + r + G::dr(gm[r]);
+            run[r] = G::run(gm[r]) && !G::far(gm[r]) && (unsigned)row0 < (unsigned)H && col0 >= 0 && col0 + 3 < W;
             const size_t idx = run[r] ? (size_t)row0 * W + col0 : (size_t)H * W;
 #pragma unroll
             for (int c = 0; c < CH; ++c)
@@ -1175,16 +1243,17 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
 
     float rr[5][CH];
     const int ya = max(y0 - 1, 0);
-    const uint32_t m0 = ((const uint32_t*)(grp0 + (size_t)ya * w))[3];
-    uint32_t mc[4];
-    load_groups(y0, mc);
+    // long entry of the last group of the LR row above (checked below)
+    const uint2 m0 = make_uint2(((const uint32_t*)(grp0 + grp_plane + (size_t)ya * w))[3],
+                                ((const uint32_t*)(grp0 + 2 * grp_plane + (size_t)ya * w))[3]);
+    uint2 mc[4];
     __syncthreads();
     {
         // HR row 4*y0 - 2 is the last of the LR row above (for y0 = 0 it reflects to row 2, the last of
         // LR row 0); its group's own row is N = 4*ya + 2
         const int N = 4 * ya + 2;
         float4 a[CH];
-        if (!fetch(m0, N - rbase, 0, true, a))
+        if (!fetch(std::true_type{}, m0, N - rbase, 0, true, a))
             fetch_global(m0, N, a);
         row_pass(a, rr[0]);
     }
@@ -1199,6 +1268,7 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
     // latency in front of every row (the kind decides the row's code path).
     uint32_t kinds = flags[(size_t)min(y0 + lane, h - 1) * strips_x];
     uint8_t place = (uint8_t)__builtin_amdgcn_readlane((int)kinds, 0);
+    load_groups(y0, place, mc);
     uint32_t sg_above = 0; // sign word of the LR row before the current one
 #ifdef SRX_STAMPS
     unsigned long long t_compute = 0, t_put = 0, t_barrier = 0, t_prologue = SRX_TICK() - t_begin;
@@ -1217,8 +1287,8 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
         const uint8_t place_next = (uint8_t)__builtin_amdgcn_readlane((int)kinds, ahead & 63);
         float4 sv[kSlots];
         batch_load(more ? 4 * y + 3 + kFwdMy : H, sv);
-        uint32_t mn[4];
-        load_groups(min(y + 1, h - 1), mn);
+        uint2 mn[4];
+        load_groups(min(y + 1, h - 1), place_next, mn);
         const y_pack yn = *(const y_pack*)(yk + (size_t)min(y + 1, h - 1) * w * CH);
 
         if (place == kRowIdentity)
@@ -1250,10 +1320,27 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
                 row_pass(a[r], rr[r + 1]);
             }
         }
-        else if (place != kRowInside)
+        else if (place == kRowOutside)
         {
             float4 a[4][CH];
             fetch_global_rows(mc, 4 * y - 1, a);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                row_pass(a[r], rr[r + 1]);
+        }
+        else if (place == kRowMixed)
+        {
+            // the lanes that find their pixels in the window read them there; the others (a few) gather from
+            // global memory, all four groups' loads in flight before the first row pass
+            float4 a[4][CH];
+            bool found[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                found[r] = fetch(std::true_type{}, mc[r], kFwdMy + 1 + r, s, true, a[r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (!found[r])
+                    fetch_global(mc[r], 4 * y - 1 + r, a[r]);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 row_pass(a[r], rr[r + 1]);
@@ -1264,7 +1351,7 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
             float4 a[4][CH];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                fetch(mc[r], kFwdMy + 1 + r, s, false, a[r]);
+                fetch(std::false_type{}, mc[r], kFwdMy + 1 + r, s, false, a[r]);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 row_pass(a[r], rr[r + 1]);
@@ -2049,7 +2136,7 @@ static int launch_group_maps(const int16_t* bwd_map, uint32_t* dec_bwd, size_t h
         return rc;
     const int hr_rows = (int)(hr_px / hr_cols), w = hr_cols / 4, h = hr_rows / 4;
     const int strips_x = (w + kFwdStrip - 1) / kFwdStrip;
-    hipLaunchKernelGGL(k_group_flags, dim3(strips_x, h), dim3(64), 0, st, dec_bwd, (uint8_t*)(dec_bwd + hr_px / 4),
+    hipLaunchKernelGGL(k_group_flags, dim3(strips_x, h), dim3(64), 0, st, dec_bwd, (uint8_t*)(dec_bwd + 3 * (hr_px / 4)),
                        hr_rows, hr_cols, strips_x);
     return check_launch("group_flags");
 }
