@@ -34,6 +34,6 @@ for n in sorted(set(fetch) & set(write)):
         "traffic_bytes_per_launch": 2 * fetch[n] * 1024 + write[n] * 1024,
     }
 json.dump({"note": "mean per launch; traffic = 2 * FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE correction)",
-           "workload": "960x540 RGB -> 3840x2160, window 9 (scripts/quick_time.py)", "kernels": out},
+           "workload": "960x540 RGB -> 3840x2160, window 9 (the solver launches of the command the passes were run on)", "kernels": out},
           open(sys.argv[3], 'w'), indent=1)
 print(json.dumps(out, indent=1))
