@@ -99,7 +99,7 @@ int launch_sign_unpair(const uint32_t* pairs, uint32_t* plain, int lr_rows, int 
 // and writes pair planes.  Otherwise the generic kernel runs: plain sign planes, X interleaved
 // (generic_plane_stride 0) or planar with that plane stride.
 // y_bytes (optional): the same LR frames as 8-bit originals (rows x cols x ch bytes each); the specialised
-// scale-4 kernel then reads those instead of the float copies (same values, a quarter of the bytes).
+// scale-4 and scale-2 kernels then read those instead of the float copies (same values, a quarter of the bytes).
 int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const PtrList& raw_bwd,
                         const PtrList* dec_bwd, const PtrList& y, const MutPtrList& signs, int K, int scale,
                         const GaussK& g, size_t generic_plane_stride, hipStream_t st,

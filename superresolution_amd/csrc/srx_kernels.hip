@@ -1443,7 +1443,7 @@ __device__ __forceinline__ float from_right_lane(float v)
 #endif
 constexpr int kFwd2Strip = 62, kFwd2Rows = SRX_A2S_ROWS;
 
-template <int CH>
+template <int CH, bool Y8>
 __global__ __launch_bounds__(64) void k_forward_sign_s2(const float* __restrict__ X, int H, int W, size_t ps,
                                                         PtrList bwd_maps, PtrList ys, MutPtrList signs, int K, GaussK g,
                                                         int strips_x, unsigned n_items)
@@ -1464,7 +1464,8 @@ __global__ __launch_bounds__(64) void k_forward_sign_s2(const float* __restrict_
     const bool mirror = x == -1; // delivers columns 2 and 1
     const int col0 = mirror ? 2 : 2 * xl, col1 = mirror ? 1 : 2 * xl + 1;
     const short2* map = (const short2*)bwd_maps.p[k];
-    const float* yk = (const float*)ys.p[k] + (size_t)xl * CH;
+    typedef typename std::conditional<Y8, uint8_t, float>::type y_elem; // Y8: the 8-bit originals of the LR frames
+    const y_elem* yk = (const y_elem*)ys.p[k] + (size_t)xl * CH;
     uint32_t* sp = (uint32_t*)signs.p[k] + xl;
     const float k0 = g.k[2], k1 = g.k[3], k2 = g.k[4];
     const unsigned zero_px = (unsigned)(H * W);
@@ -1510,7 +1511,7 @@ __global__ __launch_bounds__(64) void k_forward_sign_s2(const float* __restrict_
         float yv[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c)
-            yv[c] = yk[(size_t)y * w * CH + c];
+            yv[c] = (float)yk[(size_t)y * w * CH + c];
         hr_row(2 * y + 1, rr[3]);
         hr_row(2 * y + 2, rr[4]);
         uint32_t sg = 0;
@@ -2314,12 +2315,21 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
         const int strips_x = (w + kFwd2Strip - 1) / kFwd2Strip, row_groups = (h + kFwd2Rows - 1) / kFwd2Rows;
         const unsigned n_items = (unsigned)strips_x * row_groups * K;
         const dim3 gr(xcd_grid(n_items)), b(64);
-        if (ch == 1)
-            hipLaunchKernelGGL(k_forward_sign_s2<1>, gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride, raw_bwd, y,
-                               signs, K, g, strips_x, n_items);
+        if (y_bytes)
+        {
+            if (ch == 1)
+                hipLaunchKernelGGL((k_forward_sign_s2<1, true>), gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride,
+                                   raw_bwd, *y_bytes, signs, K, g, strips_x, n_items);
+            else
+                hipLaunchKernelGGL((k_forward_sign_s2<3, true>), gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride,
+                                   raw_bwd, *y_bytes, signs, K, g, strips_x, n_items);
+        }
+        else if (ch == 1)
+            hipLaunchKernelGGL((k_forward_sign_s2<1, false>), gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride,
+                               raw_bwd, y, signs, K, g, strips_x, n_items);
         else
-            hipLaunchKernelGGL(k_forward_sign_s2<3>, gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride, raw_bwd, y,
-                               signs, K, g, strips_x, n_items);
+            hipLaunchKernelGGL((k_forward_sign_s2<3, false>), gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride,
+                               raw_bwd, y, signs, K, g, strips_x, n_items);
         return check_launch("forward_sign_s2");
     }
     const size_t tile_lds = forward_tile_lds_bytes(ch, scale, g.n);

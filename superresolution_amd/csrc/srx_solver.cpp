@@ -364,7 +364,7 @@ int Solver::run(const float* const* y, const float* const* rel, int K, int base_
     PtrList fwd{}, bwd{}, dfwd{}, dbwd{}, ys{}, ys8{}, sg{};
     MutPtrList sgm{};
     // 8-bit originals of the frames, announced for this call only (byte_frames)
-    const bool have_bytes = fastA && announced_bytes == K;
+    const bool have_bytes = (fastA || (fastB && s == 2)) && announced_bytes == K;
     for (int k = 0; k < K; ++k)
     {
         if (int rc = launch_build_maps(rel[k], rows, cols, s, t, fwd_maps_[k].as<int16_t>(),
