@@ -492,7 +492,7 @@ def bench_tvl1(args):
         bytes_pair = 64.0 * float(np.mean(work))  # 16 floats read or written per pixel and inner iteration
         per_pair_s = elapsed / args.steps
         line = {
-            "metric": "TV-L1 flow stage, 1920x1080 grey frame pairs per second",
+            "metric": f"TV-L1 flow stage, {cols}x{rows} grey frame pairs per second",
             "value": R.world * args.steps / elapsed,
             "unit": "pairs/s",
             "n_gpus": R.world,

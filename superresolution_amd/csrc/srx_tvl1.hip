@@ -587,14 +587,14 @@ __global__ __launch_bounds__(256) void k_tvl1_iter4(Tvl1Planes P, int rows, int 
 //   iterations up to j from that set and writes the result over the other one - the same set as in the case
 //   above - without touching err[];
 //   j is older than that: it returns.
-template <int KT, int TW, int TH>
-__global__ __launch_bounds__(256) void k_tvl1_multi(Tvl1Planes P, int rows, int cols, float l_t, float theta,
+template <int KT, int TW, int TH, int NT>
+__global__ __launch_bounds__(NT, NT == 256 ? 4 : 4) void k_tvl1_multi(Tvl1Planes P, int rows, int cols, float l_t, float theta,
                                                      float taut, unsigned long long* __restrict__ err, int n_err,
                                                      int it0, int n_iter, unsigned long long thr)
 {
-    constexpr int RW = TW + 2 * KT, RH = TH + 2 * KT, CELLS = RW * RH, PER = (CELLS + 255) / 256;
+    constexpr int RW = TW + 2 * KT, RH = TH + 2 * KT, CELLS = RW * RH, PER = (CELLS + NT - 1) / NT;
     __shared__ float s_p11[CELLS], s_p21[CELLS], s_p12[CELLS], s_p22[CELLS], s_u1[CELLS], s_u2[CELLS];
-    __shared__ unsigned long long s_err[KT][4];
+    __shared__ unsigned long long s_err[KT][NT / 64];
     __shared__ int s_first;
     const int tid = threadIdx.x;
     if (tid < 64)
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(256) void k_tvl1_multi(Tvl1Planes P, int rows, int 
 #pragma unroll
     for (int i = 0; i < PER; ++i)
     {
-        const int c = tid + 256 * i;
+        const int c = tid + NT * i;
         const int cy = c / RW, cx = c - cy * RW;
         const int gx = x0 + cx, gy = y0 + cy;
         inside[i] = c < CELLS && gx >= 0 && gx < cols && gy >= 0 && gy < rows;
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256) void k_tvl1_multi(Tvl1Planes P, int rows, int 
 #pragma unroll
             for (int i = 0; i < PER; ++i)
             {
-                const int c = tid + 256 * i;
+                const int c = tid + NT * i;
                 if (!inside[i])
                     continue;
                 const int cy = c / RW, cx = c - cy * RW;
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(256) void k_tvl1_multi(Tvl1Planes P, int rows, int 
 #pragma unroll
             for (int i = 0; i < PER; ++i)
             {
-                const int c = tid + 256 * i;
+                const int c = tid + NT * i;
                 if (!inside[i])
                     continue;
                 const int cy = c / RW, cx = c - cy * RW;
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) void k_tvl1_multi(Tvl1Planes P, int rows, int 
 #pragma unroll
     for (int i = 0; i < PER; ++i)
     {
-        const int c = tid + 256 * i;
+        const int c = tid + NT * i;
         const int cy = c / RW, cx = c - cy * RW;
         if (inside[i] && cx >= KT && cx < KT + TW && cy >= KT && cy < KT + TH)
         {
@@ -740,7 +740,13 @@ __global__ __launch_bounds__(256) void k_tvl1_multi(Tvl1Planes P, int rows, int 
     }
     __syncthreads();
     if (tid < KT && tid < n_iter)
-        atomicAdd(&err[it0 + tid], s_err[tid][0] + s_err[tid][1] + s_err[tid][2] + s_err[tid][3]);
+    {
+        unsigned long long sum = 0;
+#pragma unroll
+        for (int wv = 0; wv < NT / 64; ++wv)
+            sum += s_err[tid][wv];
+        atomicAdd(&err[it0 + tid], sum);
+    }
 }
 
 // cv::resize(INTER_LINEAR) of the two flow planes to the next finer level, times 2
@@ -1000,10 +1006,10 @@ int Tvl1::calc_gray(const float* I0, const float* I1, int rows, int cols, const 
                                            l_t, theta, taut, m.err.as<unsigned long long>(), bidx, thr);
                 }
                 else if (size_class == 1)
-                    hipLaunchKernelGGL((k_tvl1_multi<4, 32, 32>), gm, dim3(256), 0, st, P, R, C, l_t, theta, taut,
+                    hipLaunchKernelGGL((k_tvl1_multi<4, 32, 32, 256>), gm, dim3(256), 0, st, P, R, C, l_t, theta, taut,
                                        m.err.as<unsigned long long>(), iters, first, count, thr);
                 else
-                    hipLaunchKernelGGL((k_tvl1_multi<8, 16, 16>), gm, dim3(256), 0, st, P, R, C, l_t, theta, taut,
+                    hipLaunchKernelGGL((k_tvl1_multi<8, 16, 16, 1024>), gm, dim3(1024), 0, st, P, R, C, l_t, theta, taut,
                                        m.err.as<unsigned long long>(), iters, first, count, thr);
             };
             // Launches are queued in batches; the error values are looked at after each batch.  The queued
