@@ -1088,9 +1088,14 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
         const bool lng = kind == kRowMixed || kind == kRowOutside;
         const uint4* p0 = grp0 + (size_t)y * w + (lng ? grp_plane : 0);
         const uint4 a0 = stream_load(p0);
-        uint4 a1 = make_uint4(0u, 0u, 0u, 0u);
-        if (lng) // the same for all lanes, and rare
-            a1 = stream_load(p0 + grp_plane);
+        // The second word of a long row comes through a buffer descriptor whose size is zero for a short row: the
+        // load is then answered with zeros without touching memory.  (The same load under a branch makes the
+        // compiler wait for every load in flight right behind it, and a row that is followed by a long row then
+        // pays a whole memory latency.)
+        const __amdgpu_buffer_rsrc_t second = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(grp_base + 2 * grp_plane), 0, lng ? (int)(grp_plane * sizeof(uint4)) : 0, 0x00027000);
+        const v4u b1 = __builtin_amdgcn_raw_buffer_load_b128(second, (int)(((size_t)y * w + xl) * sizeof(uint4)), 0, 0);
+        const uint4 a1 = make_uint4(b1.x, b1.y, b1.z, b1.w);
         m[0] = make_uint2(a0.x, a1.x), m[1] = make_uint2(a0.y, a1.y);
         m[2] = make_uint2(a0.z, a1.z), m[3] = make_uint2(a0.w, a1.w);
     };
