@@ -149,6 +149,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 // Loads and stores of data that is touched once per launch (maps, signs on their way out): marked
 // non-temporal so that they do not push the lines of X, which every window frame gathers again, out of L2.
@@ -1060,14 +1061,19 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
         p_lds[i] = c * kFwdRowBytes + 4 * q;
         p_src[i] = c * ps + (size_t)(p_col[i] ? col : 0);
     }
+    // Through a buffer descriptor over all planes of X: a piece that is not this thread's, or lies outside the
+    // image, is read at an offset beyond the buffer and comes back as zeros - no load sits under a branch.
+    const __amdgpu_buffer_rsrc_t x_planes =
+        __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)((size_t)CH * ps * sizeof(float)), 0x00027000);
     auto batch_load = [&](int row_first, float4 (&v)[kSlots]) {
 #pragma unroll
         for (int i = 0; i < kSlots; ++i)
         {
             const int row = row_first + p_rr[i];
-            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p_own[i] && p_col[i] && (unsigned)row < (unsigned)H)
-                v[i] = *(const float4*)(X + p_src[i] + (size_t)row * W);
+            const bool real = p_own[i] && p_col[i] && (unsigned)row < (unsigned)H;
+            const unsigned at = real ? (unsigned)((p_src[i] + (size_t)row * W) * sizeof(float)) : 0xFFFFFFF0u;
+            const v4f q = __builtin_amdgcn_raw_buffer_load_b128(x_planes, (int)at, 0, 0);
+            v[i] = make_float4(q.x, q.y, q.z, q.w);
         }
     };
     auto batch_put = [&](int slot_first, const float4 (&v)[kSlots]) {
@@ -1086,16 +1092,19 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
     const size_t grp_plane = (size_t)h * w;
     auto load_groups = [&](int y, uint8_t kind, uint2 (&m)[4]) {
         const bool lng = kind == kRowMixed || kind == kRowOutside;
-        const uint4* p0 = grp0 + (size_t)y * w + (lng ? grp_plane : 0);
-        const uint4 a0 = stream_load(p0);
-        // The second word of a long row comes through a buffer descriptor whose size is zero for a short row: the
-        // load is then answered with zeros without touching memory.  (The same load under a branch makes the
-        // compiler wait for every load in flight right behind it, and a row that is followed by a long row then
-        // pays a whole memory latency.)
+        // Both words come through buffer descriptors whose size is zero when the word is not needed (no entry at
+        // all for an identity row, no second word for a short row): such a load is answered with zeros without
+        // touching memory.  (The same loads under branches make the compiler wait for every load in flight right
+        // behind them, and a row that is followed by a long row then pays a whole memory latency.)
+        const int plane_bytes = (int)(grp_plane * sizeof(uint4));
+        const int at = (int)(((size_t)y * w + xl) * sizeof(uint4));
+        const __amdgpu_buffer_rsrc_t first = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(grp_base + (lng ? grp_plane : 0)), 0, kind == kRowIdentity ? 0 : plane_bytes, 0x00027000);
         const __amdgpu_buffer_rsrc_t second = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(grp_base + 2 * grp_plane), 0, lng ? (int)(grp_plane * sizeof(uint4)) : 0, 0x00027000);
-        const v4u b1 = __builtin_amdgcn_raw_buffer_load_b128(second, (int)(((size_t)y * w + xl) * sizeof(uint4)), 0, 0);
-        const uint4 a1 = make_uint4(b1.x, b1.y, b1.z, b1.w);
+            (void*)(grp_base + 2 * grp_plane), 0, lng ? plane_bytes : 0, 0x00027000);
+        const v4u b0 = __builtin_amdgcn_raw_buffer_load_b128(first, at, 0, 2 /* streaming */);
+        const v4u b1 = __builtin_amdgcn_raw_buffer_load_b128(second, at, 0, 2);
+        const uint4 a0 = make_uint4(b0.x, b0.y, b0.z, b0.w), a1 = make_uint4(b1.x, b1.y, b1.z, b1.w);
         m[0] = make_uint2(a0.x, a1.x), m[1] = make_uint2(a0.y, a1.y);
         m[2] = make_uint2(a0.z, a1.z), m[3] = make_uint2(a0.w, a1.w);
     };
@@ -2243,8 +2252,10 @@ int launch_sign_unpair(const uint32_t* pairs, uint32_t* plain, int lr_rows, int 
 
 bool forward_fast_eligible(int hr_rows, int hr_cols, int ch, int scale, const GaussK& g)
 {
+    // (the kernel reaches X and the group map through buffer descriptors: 31-bit byte offsets)
+    const size_t hr_px = (size_t)hr_rows * hr_cols;
     return scale == 4 && g.n == 5 && (ch == 1 || ch == 3) && hr_rows % 4 == 0 && hr_cols % 4 == 0 &&
-           hr_rows <= kGrpMaxDim && hr_cols <= kGrpMaxDim;
+           hr_rows <= kGrpMaxDim && hr_cols <= kGrpMaxDim && (size_t)ch * (hr_px + 4) * sizeof(float) < 0x7FFFFFF0u;
 }
 
 int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const PtrList& raw_bwd,
