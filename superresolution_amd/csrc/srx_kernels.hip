@@ -43,6 +43,7 @@
 
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -1545,6 +1546,176 @@ __global__ __launch_bounds__(64) void k_forward_sign_s2(const float* __restrict_
     }
 }
 
+// The same chain with two LR columns (four HR columns) per lane, for images whose HR width is a multiple
+// of 4.  A vector load costs the CU's address unit 16 cycles per wave whatever its width (only a wave of
+// consecutive dwords is cheaper), and the kernel above is bound by exactly that; this one reads a lane's
+// four map entries of an HR row with one 16-byte load and their pixels with one 16-byte load per plane
+// where the four sources are consecutive in X.  Where they are not (a rounding step of the motion inside
+// the lane's four pixels), a second 16-byte load ending at the fourth pixel's source covers every pattern
+// with one step; other patterns load pixel by pixel.  Pixels outside the image read the four zero pixels
+// behind the plane.  Lane l holds HR columns c0 .. c0+3, c0 = 2*x0 - 4 + 4*l; lanes 0 and 63 only serve as
+// neighbours: lane 0 of the first strip reads columns 0..3 and delivers columns 2, 1 in the places of -2, -1,
+// the lane at c0 = W reads columns W-4 .. W-1 and delivers column W-2 in the place of W.  The map entries and
+// the LR pixels of the next LR row are loaded before the pixels of the current one are gathered.
+constexpr int kFwd2Cols = 124;
+// SRX_FWD_S2_NARROW in the environment selects the one-column-per-lane kernel (for comparisons)
+static const bool g_forward_s2_wide = std::getenv("SRX_FWD_S2_NARROW") == nullptr;
+
+template <int CH, bool Y8> struct YPair;
+template <> struct YPair<1, true>
+{
+    uint16_t v;
+    __device__ __forceinline__ float get(int j, int) const { return (float)((v >> (8 * j)) & 0xFF); }
+};
+template <> struct __attribute__((packed, aligned(2))) YPair<3, true>
+{
+    uint32_t lo;
+    uint16_t hi;
+    __device__ __forceinline__ float get(int j, int c) const
+    {
+        const int at = 3 * j + c;
+        return (float)(at < 4 ? (lo >> (8 * at)) & 0xFF : (hi >> (8 * (at - 4))) & 0xFF);
+    }
+};
+template <int CH> struct __attribute__((packed, aligned(4))) YPair<CH, false>
+{
+    float v[2 * CH];
+    __device__ __forceinline__ float get(int j, int c) const { return v[CH * j + c]; }
+};
+
+template <int CH, bool Y8>
+__global__ __launch_bounds__(64) void k_forward_sign_s2w(const float* __restrict__ X, int H, int W, size_t ps,
+                                                         PtrList bwd_maps, PtrList ys, MutPtrList signs, int K, GaussK g,
+                                                         int strips_x, unsigned n_items)
+{
+    const unsigned item = xcd_contiguous(blockIdx.x, n_items);
+    if (item >= n_items)
+        return;
+    const int k = item % K;
+    const unsigned tile = item / K;
+    const int strip = tile % strips_x, rg = tile / strips_x;
+    const int h = H >> 1, w = W >> 1;
+    const int lane = threadIdx.x;
+    const int x0 = strip * kFwd2Cols, y0 = rg * kFwd2Rows;
+    const int y1 = min(y0 + kFwd2Rows, h);
+    const int xa = x0 - 2 + 2 * lane; // the lane's LR columns are xa, xa + 1
+    const int c0 = 2 * xa;
+    const bool left = c0 < 0, right = c0 == W;
+    const int cl = min(max(c0, 0), W - 4);
+    const int xl = min(max(xa, 0), w - 2);
+    const bool owner = lane >= 1 && lane <= kFwd2Cols / 2 && xa < w;
+    const uint4* map = (const uint4*)((const short2*)bwd_maps.p[k] + cl);
+    typedef typename std::conditional<Y8, uint8_t, float>::type y_elem;
+    typedef YPair<CH, Y8> y_pair;
+    const y_elem* yk = (const y_elem*)ys.p[k] + (size_t)xl * CH;
+    uint32_t* sp = (uint32_t*)signs.p[k] + xl;
+    const float k0 = g.k[2], k1 = g.k[3], k2 = g.k[4];
+    const unsigned zero_px = (unsigned)(H * W);
+    const int row_quads = W >> 2;
+
+    auto entries = [&](int Y) { return stream_load(map + (size_t)reflect101(Y, H) * row_quads); };
+    // row pass of an HR row from the lane's four map entries: out[0] for LR column xa, out[1] for xa + 1
+    auto hr_row = [&](const uint4 e, float (&out)[2][CH]) {
+        const uint32_t ev[4] = {e.x, e.y, e.z, e.w};
+        unsigned i[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+            const int mx = (int)(short)(ev[j] & 0xFFFF), my = (int)ev[j] >> 16;
+            const bool in = (unsigned)mx < (unsigned)W && (unsigned)my < (unsigned)H;
+            i[j] = in ? (unsigned)(my * W + mx) : zero_px + j;
+        }
+        float a[4][CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+        {
+            const packed_floats<4> v = *(const packed_floats<4>*)(X + c * ps + i[0]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                a[j][c] = v.v[j];
+        }
+        const bool ok1 = i[1] == i[0] + 1, ok2 = i[2] == i[0] + 2, ok3 = i[3] == i[0] + 3;
+        if (__builtin_amdgcn_ballot_w64(!(ok1 && ok2 && ok3)) != 0)
+        {
+            const unsigned ib = max(i[3], 3u) - 3;
+            const bool b1 = i[1] == ib + 1, b2 = i[2] == ib + 2, b3 = i[3] == ib + 3;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+            {
+                packed_floats<4> v = *(const packed_floats<4>*)(X + c * ps + ib);
+                asm volatile("" : "+v"(v.v[1]), "+v"(v.v[2]), "+v"(v.v[3])); // one 16-byte load, not a load per condition
+                a[1][c] = ok1 ? a[1][c] : v.v[1];
+                a[2][c] = ok2 ? a[2][c] : v.v[2];
+                a[3][c] = ok3 ? a[3][c] : v.v[3];
+            }
+            if (__builtin_amdgcn_ballot_w64(!((ok1 || b1) && (ok2 || b2) && (ok3 || b3))) != 0)
+            {
+                if (!(ok1 || b1))
+#pragma unroll
+                    for (int c = 0; c < CH; ++c)
+                        a[1][c] = X[c * ps + i[1]];
+                if (!(ok2 || b2))
+#pragma unroll
+                    for (int c = 0; c < CH; ++c)
+                        a[2][c] = X[c * ps + i[2]];
+                if (!(ok3 || b3))
+#pragma unroll
+                    for (int c = 0; c < CH; ++c)
+                        a[3][c] = X[c * ps + i[3]];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+        {
+            a[3][c] = left ? a[1][c] : a[3][c];
+            a[0][c] = right ? a[2][c] : a[0][c];
+            const float l3 = from_left_lane(a[3][c]), l2 = from_left_lane(a[2][c]), r0 = from_right_lane(a[0][c]);
+            float sum = a[0][c] * k0;
+            sum += (l3 + a[1][c]) * k1;
+            sum += (l2 + a[2][c]) * k2;
+            out[0][c] = sum;
+            sum = a[2][c] * k0;
+            sum += (a[1][c] + a[3][c]) * k1;
+            sum += (a[0][c] + r0) * k2;
+            out[1][c] = sum;
+        }
+    };
+
+    float rr[5][2][CH];
+    hr_row(entries(2 * y0 - 2), rr[0]);
+    hr_row(entries(2 * y0 - 1), rr[1]);
+    hr_row(entries(2 * y0), rr[2]);
+    uint4 e3 = entries(2 * y0 + 1), e4 = entries(2 * y0 + 2);
+    y_pair yv = *(const y_pair*)(yk + (size_t)y0 * w * CH);
+    for (int y = y0; y < y1; ++y)
+    {
+        const int yn = min(y + 1, h - 1);
+        const uint4 n3 = entries(2 * yn + 1), n4 = entries(2 * yn + 2);
+        const y_pair ynext = *(const y_pair*)(yk + (size_t)yn * w * CH);
+        hr_row(e3, rr[3]);
+        hr_row(e4, rr[4]);
+        uint32_t sg[2] = {0, 0};
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+            {
+                float sum = rr[2][j][c] * k0;
+                sum += (rr[1][j][c] + rr[3][j][c]) * k1;
+                sum += (rr[0][j][c] + rr[4][j][c]) * k2;
+                sg[j] |= (uint32_t)((int)dsign(yv.get(j, c), sum) + 1) << (10 * c);
+            }
+        if (owner)
+            stream_store((uint2*)(sp + (size_t)y * w), sg[0], sg[1]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                rr[0][j][c] = rr[2][j][c], rr[1][j][c] = rr[3][j][c], rr[2][j][c] = rr[4][j][c];
+        e3 = n3, e4 = n4, yv = ynext;
+    }
+}
+
 // Integer weights of the transposed 5-tap blur for dyadic kernels (k*16 integer):
 // per weight-table index the weights of the 2x2 block of sign cells, in units of
 // 1/256 and in the order of a pair-plane read, and their sum (the last entry is
@@ -2328,7 +2499,25 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
         hr_rows % 2 == 0 && hr_cols % 2 == 0 && (size_t)hr_rows * hr_cols < (1u << 31))
     {
         const int w = hr_cols / 2, h = hr_rows / 2;
-        const int strips_x = (w + kFwd2Strip - 1) / kFwd2Strip, row_groups = (h + kFwd2Rows - 1) / kFwd2Rows;
+        const int row_groups = (h + kFwd2Rows - 1) / kFwd2Rows;
+        if (hr_cols % 4 == 0 && g_forward_s2_wide)
+        {
+            const int strips_x = (w + kFwd2Cols - 1) / kFwd2Cols;
+            const unsigned n_items = (unsigned)strips_x * row_groups * K;
+            const dim3 gr(xcd_grid(n_items)), b(64);
+#define SRX_S2W(CHN, BYTES, YS) hipLaunchKernelGGL((k_forward_sign_s2w<CHN, BYTES>), gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride, raw_bwd, YS, signs, K, g, strips_x, n_items)
+            if (y_bytes && ch == 1)
+                SRX_S2W(1, true, *y_bytes);
+            else if (y_bytes)
+                SRX_S2W(3, true, *y_bytes);
+            else if (ch == 1)
+                SRX_S2W(1, false, y);
+            else
+                SRX_S2W(3, false, y);
+#undef SRX_S2W
+            return check_launch("forward_sign_s2w");
+        }
+        const int strips_x = (w + kFwd2Strip - 1) / kFwd2Strip;
         const unsigned n_items = (unsigned)strips_x * row_groups * K;
         const dim3 gr(xcd_grid(n_items)), b(64);
         if (y_bytes)

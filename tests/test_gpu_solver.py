@@ -64,6 +64,12 @@ CASES = [
     (2, 16, 20, 1, 1, dict(iterations=6, lambda_=0.0)),
     (1, 16, 20, 3, 0, dict(iterations=6)),
     (17, 14, 18, 3, 8, dict(iterations=4, scale=2)),
+    # scale 2: an HR width that is not a multiple of 4 (one LR column per lane), more than one strip of either
+    # forward kernel, one channel
+    (3, 26, 31, 3, 0, dict(iterations=6, scale=2)),
+    (3, 10, 130, 3, 1, dict(iterations=4, scale=2)),
+    (3, 12, 66, 1, 1, dict(iterations=4, scale=2)),
+    (3, 12, 65, 1, 1, dict(iterations=4, scale=2)),
     # more window frames than one block of the scale-4 forward kernel takes (two passes over the tile),
     # and a strip boundary (more than 63 LR columns)
     (11, 12, 70, 3, 5, dict(iterations=3)),
@@ -85,14 +91,18 @@ def test_process_matches_oracle_bit_exact(rng, K, rows, cols, ch, base, kw):
     assert np.array_equal(ref_out, out.cpu().numpy())
 
 
-def test_run_with_arbitrary_relative_motions(rng):
-    """run() with motions that leave the image, so the constant-0 remap border is exercised in both directions."""
+@pytest.mark.parametrize("scale,rows,cols,ch,amp", [(4, 20, 24, 3, 4.0), (2, 20, 24, 3, 4.0), (2, 14, 132, 3, 2.0),
+                                                    (2, 14, 132, 1, 9.0), (2, 16, 33, 3, 4.0)])
+def test_run_with_arbitrary_relative_motions(rng, scale, rows, cols, ch, amp):
+    """run() with motions that leave the image, so the constant-0 remap border is exercised in both directions;
+    at scale 2 the motions also break the runs of consecutive source pixels that the forward kernel loads whole
+    (one step within a lane's four pixels, several steps, sources on both sides of the image edge)."""
     from superresolution_amd import api, ops
 
-    K, rows, cols, ch = 3, 20, 24, 3
-    p = oracle.BtvParams(iterations=10)
+    K = 3
+    p = oracle.BtvParams(iterations=10 if cols < 100 else 4, scale=scale)
     y, _ = make_case(rng, K, rows, cols, ch, p.scale, seed=5)
-    rel = [smooth_motion(rng, rows, cols, amp=4.0) for _ in range(K)]
+    rel = [smooth_motion(rng, rows, cols, amp=amp) for _ in range(K)]
     rel[1][:] = 0
     rel[0][:4] += 9.0
     ref = oracle.btvl1_run(y, rel, 1, p)
