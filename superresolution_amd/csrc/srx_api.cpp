@@ -1501,7 +1501,7 @@ SRX_API int srx_k_backproject_update(const float* X, float* X_out, int hr_rows, 
             return rc;
         for (int k = 0; k < K; ++k)
         {
-            if (int rc = dec[k].reserve(px * 4))
+            if (int rc = dec[k].reserve(dec_fwd_words(hr_rows, hr_cols, scale) * 4))
                 return rc;
             if (int rc = spad[k].reserve(padded))
                 return rc;

@@ -325,6 +325,76 @@ __global__ void k_decode_maps(const short2* __restrict__ fwd_map, int R, int C, 
     dec_fwd[o] = scale == 2 ? decode_fwd2(fwd_map[o].x, fwd_map[o].y, R, C) : decode_fwd(fwd_map[o].x, fwd_map[o].y, R, C);
 }
 
+// Scale 2: the decoded forward map made relative to the update kernel's tiles.  A tile of 64 x 16 HR pixels
+// back-projects from a small patch of every frame's sign plane (its own place shifted by the frame's motion),
+// and the update kernel stages that patch in LDS instead of gathering 3 x 3 cells per pixel and frame from
+// global memory (the texture path handles scattered dwords at an eighth of its coalesced rate, and those
+// gathers were the kernel's bound).  One block per tile: finds the bounding box of the top-left cells of the
+// tile's entries; if the boxes of all pixels fit a patch of kSgRows x kSgCols cells, the entries are rewritten
+// as bits 0..9 = (row - row0) * kSgPitch + (col - col0) (weight index unchanged) and the tile's header word
+// (behind the map, one per tile) becomes 1 << 31 | byte offset of cell (row0, col0); otherwise entries stay as
+// they are and the header is 0 (the update kernel then gathers from global memory for this tile and frame).
+constexpr int kSgRows = 12, kSgCols = 64, kSgPitch = 65, kSgWords = kSgRows * kSgPitch;
+constexpr uint32_t kSgFit = 1u << 31, kSgCellMask = 1023u;
+__global__ __launch_bounds__(256) void k_tile_relative(uint32_t* __restrict__ dec, int H, int W, int tiles_x)
+{
+    __shared__ int lo_r, hi_r, lo_c, hi_c;
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int j0 = (t % tiles_x) * kUpdTileCols, i0 = (t / tiles_x) * kUpdTileRows;
+    const int ty = tid >> 4, tx = tid & 15;
+    const bool live = i0 + ty < H && j0 + 4 * tx < W; // W is a multiple of 4
+    const int i = min(i0 + ty, H - 1), j = min(j0 + 4 * tx, W - 4);
+    const int w = W >> 1;
+    if (tid == 0)
+        lo_r = lo_c = 1 << 30, hi_r = hi_c = -1;
+    // every thread reads before any thread writes: threads beyond the image edge read a live thread's entries
+    uint4* at = (uint4*)(dec + (size_t)i * W + j);
+    const uint4 e4 = *at;
+    const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
+    int row[4], col[4];
+    bool used[4];
+    __syncthreads();
+    int mn_r = 1 << 30, mx_r = -1, mn_c = 1 << 30, mx_c = -1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+    {
+        used[q] = (e[q] >> kFwdLutShift) != kFwdLutZero;
+        const int cell = (int)((e[q] & kFwdCellMask) >> 2);
+        row[q] = cell / w, col[q] = cell - row[q] * w;
+        if (used[q])
+        {
+            mn_r = min(mn_r, row[q]), mx_r = max(mx_r, row[q]);
+            mn_c = min(mn_c, col[q]), mx_c = max(mx_c, col[q]);
+        }
+    }
+    // one set of atomics per wave
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+    {
+        mn_r = min(mn_r, __shfl_xor(mn_r, off)), mx_r = max(mx_r, __shfl_xor(mx_r, off));
+        mn_c = min(mn_c, __shfl_xor(mn_c, off)), mx_c = max(mx_c, __shfl_xor(mx_c, off));
+    }
+    if ((tid & 63) == 0 && mx_r >= 0)
+    {
+        atomicMin(&lo_r, mn_r), atomicMax(&hi_r, mx_r);
+        atomicMin(&lo_c, mn_c), atomicMax(&hi_c, mx_c);
+    }
+    __syncthreads();
+    const bool any = hi_r >= 0;
+    const int r0 = any ? lo_r : 0, c0 = any ? lo_c : 0;
+    const bool fit = !any || (hi_r - lo_r + 3 <= kSgRows && hi_c - lo_c + 3 <= kSgCols);
+    if (fit && live)
+    {
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            o[q] = (e[q] & ~kFwdCellMask) | (used[q] ? (uint32_t)((row[q] - r0) * kSgPitch + (col[q] - c0)) : 0u);
+        *at = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    if (tid == 0)
+        dec[(size_t)H * W + t] = fit ? (kSgFit | (uint32_t)(r0 * w + c0) * 4u) : 0u;
+}
+
 // group map of the backward map (layout at the top of this file); one thread per entry
 __global__ void k_group_maps(const short2* __restrict__ bwd_map, uint32_t* __restrict__ grp, int H, int W)
 {
@@ -1798,11 +1868,33 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
 //    dyadic blur kernels: every partial sum is a multiple of 1/256.  The loop is
 //    branch-free: entries outside the image carry zero weights, and the
 //    targets next to the image edge have weight-table entries of their own.
+//  * scale 2 (FOOT == 3): a target touches 3 x 3 cells of a plain sign plane.  The patch of every frame's
+//    plane that the tile's pixels reach is staged in LDS (kSgRows x kSgCols cells, placed per tile and frame by
+//    k_tile_relative, which also makes the map entries relative to it), one frame ahead of its use, one barrier
+//    per frame; the nine cells per pixel are then LDS reads.  Gathered from global memory they took 27 cycles
+//    of the texture path per 64-lane instruction and the kernel ran at that path's pace.  A tile whose entries
+//    do not fit the patch (header 0) gathers from global memory as before.
 //  * lanes are mapped to tile positions so that each lane group of a
 //    ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) reads 16
 //    consecutive 16-byte chunks of one LDS row: conflict-free at any row pitch.
 #ifndef SRX_B_WAVES
 #define SRX_B_WAVES 6
+#endif
+// waves per SIMD of the scale-2 variant (it holds two sets of staged sign cells besides the map entries)
+#ifndef SRX_B3_WAVES
+#define SRX_B3_WAVES 5
+#endif
+// the thread's own pixels read again for the update (1) instead of kept in registers across the frame loop (0)
+#ifndef SRX_B3_REREAD
+#define SRX_B3_REREAD 1
+#endif
+// frames ahead that the staged sign cells are asked for (scale-2 variant): 1 or 2
+#ifndef SRX_B3_DEPTH
+#define SRX_B3_DEPTH 1
+#endif
+// pixels whose LDS reads of sign cells are in flight together (scale-2 variant)
+#ifndef SRX_B3_LDS_PX
+#define SRX_B3_LDS_PX 2
 #endif
 #ifndef SRX_B_PARK
 #define SRX_B_PARK 2
@@ -1814,7 +1906,7 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
 
 // FOOT = cells per axis a target can touch: 2 (scale 4, pair plane) or 3 (scale 2, plain plane)
 template <int CH, int FOOT>
-__global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVES - 1) void k_backproject_update_s4(
+__global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B3_WAVES) void k_backproject_update_s4(
     const float* __restrict__ X, float* __restrict__ X_out, int H, int W, size_t ps, PtrList dec_fwd,
     PtrList signs, int K, FastW fw, BtvW bw, double tau, double lambda, int tiles_x, unsigned n_tiles)
 {
@@ -2068,6 +2160,39 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVE
     }
     else
         __syncthreads(); // the weight table
+    // ---- scale 2: the patch of each frame's sign plane that this tile back-projects from goes through LDS
+    // (k_tile_relative); the headers of all frames are fetched once, one per lane
+    static_assert(FOOT != 3 || (TYN == kUpdTileRows && TW == kUpdTileCols && kThreads == 256), "tile geometry of k_tile_relative");
+    __shared__ uint32_t sgl[FOOT == 3 ? 2 * kSgWords : 1];
+    uint32_t hdrs = 0, s_g = 0, s_l = 0;
+    uint32_t sign_last = 0;
+    if (FOOT == 3)
+    {
+        for (int k = 0; k < K; ++k)
+        {
+            const uint32_t v = ((const uint32_t*)dec_fwd.p[k])[(size_t)H * W + t];
+            hdrs = (tid & 63) == k ? v : hdrs; // every lane loads the same word
+        }
+        // a thread stages column tid & 63 of rows (tid >> 6) + 4 * it, it = 0..2, of the patch
+        s_g = (uint32_t)((tid >> 6) * (W >> 1) + (tid & 63)) * 4u;
+        s_l = (uint32_t)((tid >> 6) * kSgPitch + (tid & 63));
+        sign_last = (uint32_t)(((H >> 1) + 1) * (W >> 1) - 1) * 4u; // last cell of the spare row
+    }
+    static_assert(kSgRows * kSgCols == 3 * 256 && kSgCols == 64, "three cells per thread, one patch row per wave");
+    // cells beyond the plane are never referenced by an entry; their loads are bent to the plane's last cell
+    auto stage_load = [&](int k, uint32_t hd, uint32_t (&v)[3]) {
+        const char* base = (const char*)signs.p[k];
+        const uint32_t org = (hd & kFwdCellMask) + s_g;
+        const uint32_t four_rows = (uint32_t)(W >> 1) * 16u;
+#pragma unroll
+        for (int it = 0; it < 3; ++it)
+            v[it] = *(const uint32_t*)(base + min(org + it * four_rows, sign_last));
+    };
+    auto stage_put = [&](int buf, const uint32_t (&v)[3]) {
+#pragma unroll
+        for (int it = 0; it < 3; ++it)
+            sgl[buf * kSgWords + it * 4 * kSgPitch + s_l] = v[it];
+    };
     // ---- sum over frames of M^T H^T D^T sign, in units of 1/256
     int acc[PXT][CH];
     int bias[PXT];
@@ -2086,6 +2211,7 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVE
         for (int p = 0; p < PXT; ++p)
             accv[p] = 0;
         int pending = 0;
+        uint32_t hd_now = 0; // scale 2: header of the current frame's tile (wave-uniform)
         // one window frame: gathers through the entries in `now` while the next frame's entries arrive in `next`
         auto frame = [&](int k, const uint4& now, uint4& next) {
             if (k + 1 < K)
@@ -2115,9 +2241,37 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVE
                     bias[p] += *(const uint32_t*)(le + kFwdLutSize * 16);
                 }
             }
+            else if (hd_now & kSgFit)
+            {
+                // the tile's patch of this frame is in LDS: nine cells per pixel from there
+                const uint32_t* lb = sgl + (k & 1) * kSgWords;
+#pragma unroll
+                for (int p = 0; p < PXT; ++p)
+                {
+                    const uint32_t e = ev[p];
+                    const uint32_t* q = lb + (e & kSgCellMask);
+                    const char* le = lutb + ((e >> kFwdLutShift) & 31u) * 48u;
+                    const uint4 w0 = *(const uint4*)le, w1 = *(const uint4*)(le + 16), w2 = *(const uint4*)(le + 32);
+                    uint32_t v = accv[p];
+                    v = mad_u24(q[0], w0.x, v);
+                    v = mad_u24(q[1], w0.y, v);
+                    v = mad_u24(q[2], w0.z, v);
+                    v = mad_u24(q[kSgPitch], w0.w, v);
+                    v = mad_u24(q[kSgPitch + 1], w1.x, v);
+                    v = mad_u24(q[kSgPitch + 2], w1.y, v);
+                    v = mad_u24(q[2 * kSgPitch], w1.z, v);
+                    v = mad_u24(q[2 * kSgPitch + 1], w1.w, v);
+                    v = mad_u24(q[2 * kSgPitch + 2], w2.x, v);
+                    accv[p] = v;
+                    bias[p] += w2.y;
+                    if (SRX_B3_LDS_PX == 1 || (p & 1))
+                        __builtin_amdgcn_sched_barrier(0); // bounds the registers held by reads in flight
+                }
+            }
             else
             {
-                // three rows of three cells per pixel, two pixels at a time (register budget)
+                // (a tile whose entries did not fit the patch) three rows of three cells per pixel from global
+                // memory, two pixels at a time (register budget)
                 const size_t row_bytes = (size_t)(W >> 1) * 4;
 #pragma unroll
                 for (int p0 = 0; p0 < PXT; p0 += 2)
@@ -2163,16 +2317,53 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVE
                 pending = 0;
             }
         };
+        // scale 2: the patch of frame k+2 is asked for while frame k is worked on (two frames ahead: one frame's
+        // arithmetic is shorter than a memory latency), frame k+1's is written to the other LDS buffer behind
+        // frame k's reads; one barrier per frame.  `par` = k & 1.
+        uint32_t sv[SRX_B3_DEPTH][3];
+        auto step = [&](int k, const uint4& now, uint4& next, const int par) {
+            if (FOOT == 3)
+            {
+                const uint32_t hd_next = k + 1 < K ? (uint32_t)__builtin_amdgcn_readlane((int)hdrs, k + 1) : 0u;
+                if (SRX_B3_DEPTH == 2)
+                {
+                    const uint32_t hd_far = k + 2 < K ? (uint32_t)__builtin_amdgcn_readlane((int)hdrs, k + 2) : 0u;
+                    if (hd_far & kSgFit)
+                        stage_load(k + 2, hd_far, sv[par]);
+                }
+                else if (hd_next & kSgFit)
+                    stage_load(k + 1, hd_next, sv[0]);
+                frame(k, now, next);
+                if (hd_next & kSgFit)
+                    stage_put(par ^ 1, sv[SRX_B3_DEPTH == 2 ? par ^ 1 : 0]);
+                __syncthreads();
+                hd_now = hd_next;
+            }
+            else
+                frame(k, now, next);
+        };
+        if (FOOT == 3 && K > 0)
+        {
+            hd_now = (uint32_t)__builtin_amdgcn_readlane((int)hdrs, 0);
+            const uint32_t hd_1 = K > 1 ? (uint32_t)__builtin_amdgcn_readlane((int)hdrs, 1) : 0u;
+            if (hd_now & kSgFit)
+                stage_load(0, hd_now, sv[0]);
+            if (SRX_B3_DEPTH == 2 && (hd_1 & kSgFit))
+                stage_load(1, hd_1, sv[SRX_B3_DEPTH - 1]);
+            if (hd_now & kSgFit)
+                stage_put(0, sv[0]);
+            __syncthreads();
+        }
         // two frames per trip, the two entry registers swapping roles (no copies)
         uint4 alt = cur;
         int k = 0;
         for (; k + 1 < K; k += 2)
         {
-            frame(k, cur, alt);
-            frame(k + 1, alt, cur);
+            step(k, cur, alt, 0);
+            step(k + 1, alt, cur, 1);
         }
         if (k < K)
-            frame(k, cur, alt);
+            step(k, cur, alt, 0);
     }
     SRX_STAMP(5);
     // ---- update
@@ -2185,7 +2376,7 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B_WAVE
         // with the regulariser on, the centre pixels were kept from the tile (-0 arrives as +0, which the
         // double sum below maps to the same result); otherwise they are read here
         float cxv[PXT];
-        if (lambda > 0)
+        if (lambda > 0 && !(FOOT == 3 && SRX_B3_REREAD))
         {
 #pragma unroll
             for (int p = 0; p < PXT; ++p)
@@ -2327,6 +2518,17 @@ static int launch_group_maps(const int16_t* bwd_map, uint32_t* dec_bwd, size_t h
     return check_launch("group_flags");
 }
 
+// scale 2: entries relative to the update kernel's tiles, headers behind the map (dec_fwd_words)
+static int launch_tile_relative(uint32_t* dec_fwd, int hr_rows, int hr_cols, hipStream_t st)
+{
+    if (hr_cols % 4 != 0 || hr_cols < 8 || hr_rows < 8)
+        return 0; // the specialised update kernel does not run at such sizes (backproject_fast_eligible)
+    const int tiles_x = (hr_cols + kUpdTileCols - 1) / kUpdTileCols, tiles_y = (hr_rows + kUpdTileRows - 1) / kUpdTileRows;
+    hipLaunchKernelGGL(k_tile_relative, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, st, dec_fwd, hr_rows, hr_cols,
+                       tiles_x);
+    return check_launch("tile_relative");
+}
+
 int launch_build_maps(const float* rel, int rows, int cols, int scale, const CubicTables& t, int16_t* fwd_map,
                       int16_t* bwd_map, uint32_t* dec_fwd, uint32_t* dec_bwd, hipStream_t st)
 {
@@ -2340,6 +2542,9 @@ int launch_build_maps(const float* rel, int rows, int cols, int scale, const Cub
                        (short2*)fwd_map, (short2*)bwd_map, dec_fwd);
     if (int rc = check_launch("build_maps"))
         return rc;
+    if (dec_fwd && scale == 2)
+        if (int rc = launch_tile_relative(dec_fwd, rows * scale, cols * scale, st))
+            return rc;
     return dec_bwd ? launch_group_maps(bwd_map, dec_bwd, (size_t)rows * scale * cols * scale, cols * scale, st) : 0;
 }
 
@@ -2353,6 +2558,9 @@ int launch_decode_maps(const int16_t* fwd_map, const int16_t* bwd_map, int hr_ro
                            hr_cols, scale, dec_fwd);
         if (int rc = check_launch("decode_maps"))
             return rc;
+        if (scale == 2)
+            if (int rc = launch_tile_relative(dec_fwd, hr_rows, hr_cols, st))
+                return rc;
     }
     return dec_bwd ? launch_group_maps(bwd_map, dec_bwd, (size_t)hr_rows * hr_cols, hr_cols, st) : 0;
 }

@@ -219,6 +219,7 @@ int Solver::ensure(int K, int rows, int cols, int ch, int scale, hipStream_t st)
     const size_t sign_bytes = sign_pair_bytes(rows, cols);
     const size_t rel_bytes = (size_t)rows * cols * 2 * sizeof(float);
     const bool dec = (scale == 4 || scale == 2) && g_kernel_path == 0;
+    const size_t dec_fwd_bytes = dec_fwd_words(rows * scale, cols * scale, scale) * 4;
     if ((int)fwd_maps_.size() < K)
     {
         fwd_maps_.resize(K);
@@ -231,7 +232,7 @@ int Solver::ensure(int K, int rows, int cols, int ch, int scale, hipStream_t st)
     bool grow = x_[0].capacity() < x_bytes;
     for (int k = 0; k < K && !grow; ++k)
         grow = fwd_maps_[k].capacity() < hr_px * 4 || signs_[k].capacity() < sign_bytes ||
-               rel_[k].capacity() < rel_bytes || (dec && dec_fwd_[k].capacity() < hr_px * 4);
+               rel_[k].capacity() < rel_bytes || (dec && dec_fwd_[k].capacity() < dec_fwd_bytes);
     if (grow)
         SRX_HIP(hipStreamSynchronize(st)); // buffers about to be freed may still be in use
     for (int k = 0; k < K; ++k)
@@ -242,7 +243,7 @@ int Solver::ensure(int K, int rows, int cols, int ch, int scale, hipStream_t st)
             return rc;
         if (dec)
         {
-            if (int rc = dec_fwd_[k].reserve(hr_px * 4))
+            if (int rc = dec_fwd_[k].reserve(dec_fwd_bytes))
                 return rc;
             if (scale == 4)
                 if (int rc = dec_bwd_[k].reserve(dec_bwd_words(hr_px) * 4))
