@@ -120,11 +120,14 @@ def algorithmic_bytes(P, C, K, s):
     return fwd, bwd
 
 
-def measured_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/*_traffic.json, written by
-    scripts/pmc_traffic.py on the same workload), or None."""
+def measured_traffic(kernel, tag=""):
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/rNN_traffic.json for the
+    headline workload, profiles/rNN_<tag>_traffic.json for the others; written by scripts/pmc_traffic.py on the
+    same workload), or None."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    import re
+    pat = re.compile(r"r\d+_" + (tag + "_" if tag else "") + r"traffic\.json$")
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")) if pat.search(os.path.basename(f)))
     if not files:
         return None, None
     try:
@@ -413,7 +416,8 @@ def bench_solver(args):
             for name, what, nbytes, secs in (
                     (fwd_name, "sign(y_k - D H M_k X) of all window frames", bytes_fwd, fwd_launch_s),
                     (bwd_name, "back-projection of all window frames + BTV + update", bytes_bwd, bwd_launch_s)):
-                traffic, traffic_src = measured_traffic(name) if headline_shape else (None, None)
+                tag = {"configs[3]": "", "configs[4]": "cfg5"}.get(args.config_name)
+                traffic, traffic_src = measured_traffic(name, tag) if tag is not None else (None, None)
                 kernels[name] = {"kernel": f"{name} ({what})", "achieved": nbytes / secs / 1e9, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": nbytes / secs / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                                  "traffic_source": traffic_src, "algorithmic_bytes_per_launch": nbytes,

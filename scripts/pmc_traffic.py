@@ -1,6 +1,6 @@
 """HBM-side traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) -> JSON.
 
-usage: pmc_traffic.py <fetch pass dir> <write pass dir> <out.json>
+usage: pmc_traffic.py <fetch pass dir> <write pass dir> <out.json> [workload description]
 FETCH_SIZE and WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE tallies the 128-byte read requests of
 wide coalesced loads at 64 bytes, so it is doubled; WRITE_SIZE is taken as reported.
 """
@@ -34,6 +34,7 @@ for n in sorted(set(fetch) & set(write)):
         "traffic_bytes_per_launch": 2 * fetch[n] * 1024 + write[n] * 1024,
     }
 json.dump({"note": "mean per launch; traffic = 2 * FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE correction)",
-           "workload": "960x540 RGB -> 3840x2160, window 9 (the solver launches of the command the passes were run on)", "kernels": out},
+           "workload": sys.argv[4] if len(sys.argv) > 4 else
+           "960x540 RGB -> 3840x2160, window 9 (the solver launches of the command the passes were run on)", "kernels": out},
           open(sys.argv[3], 'w'), indent=1)
 print(json.dumps(out, indent=1))

@@ -29,6 +29,15 @@ pmc sq1 SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY SQ_BUSY_CY
 pmc sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY || exit 1
 pmc fetch FETCH_SIZE || exit 1
 pmc write WRITE_SIZE || exit 1
+# HBM traffic of the scale-2 configuration's solver kernels
+pmc5() { # tag, counters...
+  local tag=$1; shift
+  timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d $O/pmc_$tag -- python3 $R/bench.py --workload cfg5 --flow synthetic --steps 1 --warmup 0 --iterations 6 --no-cpu-baseline --no-kernel-timing > $O/pmc_$tag.log 2>&1
+  echo "pmc $tag rc=$?"
+}
+pmc5 fetch5 FETCH_SIZE || exit 1
+pmc5 write5 WRITE_SIZE || exit 1
+python3 $R/scripts/pmc_traffic.py $O/pmc_fetch5 $O/pmc_write5 $O/cfg5_traffic.json "1920x1080 RGB -> 3840x2160, scale 2, window 17 (the solver launches of the command the passes were run on)" > /dev/null
 python3 $R/scripts/pmc_summary.py $O/pmc_sq1 backproject_update forward_sign > $O/pmc_counters.txt
 python3 $R/scripts/pmc_summary.py $O/pmc_sq2 backproject_update forward_sign >> $O/pmc_counters.txt
 python3 $R/scripts/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/traffic.json > /dev/null

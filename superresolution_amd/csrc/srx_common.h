@@ -65,13 +65,19 @@ inline size_t dec_bwd_words(size_t hr_px)
 {
     return 3 * (hr_px / 4) + hr_px / 64 + 4;
 }
-// dec_fwd holds dec_fwd_words(...) words: one entry per HR pixel and, at scale 2, one word per 64 x 16 tile of the
-// update kernel behind them (where the tile's sign cells lie; see k_tile_relative)
+// dec_fwd holds dec_fwd_words(...) words: one entry per HR pixel and, at scale 2, behind them one word per 64 x 16
+// tile of the update kernel (where the tile's sign cells lie; an even number of words) and the 16-bit form of
+// the entries, relative to the tiles (see k_tile_relative)
 constexpr int kUpdTileCols = 64, kUpdTileRows = 16;
-inline size_t dec_fwd_words(int hr_rows, int hr_cols, int scale)
+inline size_t dec_fwd_tile_words(int hr_rows, int hr_cols)
 {
     const size_t tiles = (size_t)((hr_cols + kUpdTileCols - 1) / kUpdTileCols) * ((hr_rows + kUpdTileRows - 1) / kUpdTileRows);
-    return (size_t)hr_rows * hr_cols + (scale == 2 ? tiles : 0);
+    return (tiles + 1) & ~(size_t)1;
+}
+inline size_t dec_fwd_words(int hr_rows, int hr_cols, int scale)
+{
+    const size_t px = (size_t)hr_rows * hr_cols;
+    return px + (scale == 2 ? dec_fwd_tile_words(hr_rows, hr_cols) + (px + 1) / 2 : 0);
 }
 int launch_build_maps(const float* rel, int rows, int cols, int scale, const CubicTables& t, int16_t* fwd_map,
                       int16_t* bwd_map, uint32_t* dec_fwd, uint32_t* dec_bwd, hipStream_t st);

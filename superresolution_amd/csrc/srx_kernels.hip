@@ -159,6 +159,11 @@ __device__ __forceinline__ uint4 stream_load(const uint4* p)
     const v4u v = __builtin_nontemporal_load((const v4u*)p);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ uint2 stream_load(const uint2* p)
+{
+    const v2u v = __builtin_nontemporal_load((const v2u*)p);
+    return make_uint2(v.x, v.y);
+}
 __device__ __forceinline__ void stream_store(uint32_t* p, uint32_t v)
 {
     __builtin_nontemporal_store(v, p);
@@ -330,13 +335,17 @@ __global__ void k_decode_maps(const short2* __restrict__ fwd_map, int R, int C, 
 // and the update kernel stages that patch in LDS instead of gathering 3 x 3 cells per pixel and frame from
 // global memory (the texture path handles scattered dwords at an eighth of its coalesced rate, and those
 // gathers were the kernel's bound).  One block per tile: finds the bounding box of the top-left cells of the
-// tile's entries; if the boxes of all pixels fit a patch of kSgRows x kSgCols cells, the entries are rewritten
-// as bits 0..9 = (row - row0) * kSgPitch + (col - col0) (weight index unchanged) and the tile's header word
-// (behind the map, one per tile) becomes 1 << 31 | byte offset of cell (row0, col0); otherwise entries stay as
-// they are and the header is 0 (the update kernel then gathers from global memory for this tile and frame).
+// tile's entries; if the boxes of all pixels fit a patch of kSgRows x kSgCols cells, the tile's entries are
+// written a second time in a 16-bit form (behind the tile headers: half the map bytes for the update kernel to
+// read), bits 0..9 = (row - row0) * kSgPitch + (col - col0), bits 10..14 = weight-table index, and the tile's
+// header word (behind the map, one per tile) becomes 1 << 31 | byte offset of cell (row0, col0); otherwise the
+// header is 0 (the update kernel then reads the 32-bit entries and gathers from global memory for this tile
+// and frame).
 constexpr int kSgRows = 12, kSgCols = 64, kSgPitch = 65, kSgWords = kSgRows * kSgPitch;
 constexpr uint32_t kSgFit = 1u << 31, kSgCellMask = 1023u;
-__global__ __launch_bounds__(256) void k_tile_relative(uint32_t* __restrict__ dec, int H, int W, int tiles_x)
+constexpr int kSgLutShift = 10;
+__global__ __launch_bounds__(256) void k_tile_relative(uint32_t* __restrict__ dec, int H, int W, int tiles_x,
+                                                       unsigned tile_words)
 {
     __shared__ int lo_r, hi_r, lo_c, hi_c;
     const int t = blockIdx.x, tid = threadIdx.x;
@@ -347,9 +356,7 @@ __global__ __launch_bounds__(256) void k_tile_relative(uint32_t* __restrict__ de
     const int w = W >> 1;
     if (tid == 0)
         lo_r = lo_c = 1 << 30, hi_r = hi_c = -1;
-    // every thread reads before any thread writes: threads beyond the image edge read a live thread's entries
-    uint4* at = (uint4*)(dec + (size_t)i * W + j);
-    const uint4 e4 = *at;
+    const uint4 e4 = *(const uint4*)(dec + (size_t)i * W + j);
     const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
     int row[4], col[4];
     bool used[4];
@@ -388,8 +395,10 @@ __global__ __launch_bounds__(256) void k_tile_relative(uint32_t* __restrict__ de
         uint32_t o[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            o[q] = (e[q] & ~kFwdCellMask) | (used[q] ? (uint32_t)((row[q] - r0) * kSgPitch + (col[q] - c0)) : 0u);
-        *at = make_uint4(o[0], o[1], o[2], o[3]);
+            o[q] = ((e[q] >> kFwdLutShift) & 31u) << kSgLutShift |
+                   (used[q] ? (uint32_t)((row[q] - r0) * kSgPitch + (col[q] - c0)) : 0u);
+        uint2* at16 = (uint2*)(dec + (size_t)H * W + tile_words) + ((size_t)i * W + j) / 4;
+        *at16 = make_uint2(o[0] | o[1] << 16, o[2] | o[3] << 16);
     }
     if (tid == 0)
         dec[(size_t)H * W + t] = fit ? (kSgFit | (uint32_t)(r0 * w + c0) * 4u) : 0u;
@@ -1949,6 +1958,12 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B3_WAV
     uint4 cur = make_uint4(0, 0, 0, 0);
     if (K > 0)
         cur = stream_load((const uint4*)((const uint32_t*)dec_fwd.p[0] + pix));
+    // scale 2: the 16-bit entries of a tile that has them (k_tile_relative); the first frame's are fetched in both
+    // forms, the tile's header is not known yet
+    const size_t short_entries = (size_t)H * W + (((size_t)n_tiles + 1) & ~(size_t)1); // in words, from the map's start
+    uint2 cur16 = make_uint2(0, 0);
+    if (FOOT == 3 && K > 0)
+        cur16 = stream_load((const uint2*)((const uint32_t*)dec_fwd.p[0] + short_entries) + pix / 4);
 
     if (tid < kFwdLutSize)
     {
@@ -2215,7 +2230,15 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B3_WAV
         // one window frame: gathers through the entries in `now` while the next frame's entries arrive in `next`
         auto frame = [&](int k, const uint4& now, uint4& next) {
             if (k + 1 < K)
-                next = stream_load((const uint4*)((const uint32_t*)dec_fwd.p[k + 1] + pix));
+            {
+                if (FOOT == 3 && ((uint32_t)__builtin_amdgcn_readlane((int)hdrs, k + 1) & kSgFit))
+                {
+                    const uint2 n16 = stream_load((const uint2*)((const uint32_t*)dec_fwd.p[k + 1] + short_entries) + pix / 4);
+                    next = make_uint4(n16.x, n16.y, 0, 0);
+                }
+                else
+                    next = stream_load((const uint4*)((const uint32_t*)dec_fwd.p[k + 1] + pix));
+            }
             const char* sg = (const char*)signs.p[k];
             const uint32_t ev[PXT] = {now.x, now.y, now.z, now.w};
             if (FOOT == 2)
@@ -2248,9 +2271,9 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B3_WAV
 #pragma unroll
                 for (int p = 0; p < PXT; ++p)
                 {
-                    const uint32_t e = ev[p];
+                    const uint32_t e = ev[p >> 1] >> (16 * (p & 1)); // 16-bit entries, two to a word
                     const uint32_t* q = lb + (e & kSgCellMask);
-                    const char* le = lutb + ((e >> kFwdLutShift) & 31u) * 48u;
+                    const char* le = lutb + ((e >> kSgLutShift) & 31u) * 48u;
                     const uint4 w0 = *(const uint4*)le, w1 = *(const uint4*)(le + 16), w2 = *(const uint4*)(le + 32);
                     uint32_t v = accv[p];
                     v = mad_u24(q[0], w0.x, v);
@@ -2345,6 +2368,8 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B3_WAV
         if (FOOT == 3 && K > 0)
         {
             hd_now = (uint32_t)__builtin_amdgcn_readlane((int)hdrs, 0);
+            if (hd_now & kSgFit)
+                cur = make_uint4(cur16.x, cur16.y, 0, 0);
             const uint32_t hd_1 = K > 1 ? (uint32_t)__builtin_amdgcn_readlane((int)hdrs, 1) : 0u;
             if (hd_now & kSgFit)
                 stage_load(0, hd_now, sv[0]);
@@ -2525,7 +2550,7 @@ static int launch_tile_relative(uint32_t* dec_fwd, int hr_rows, int hr_cols, hip
         return 0; // the specialised update kernel does not run at such sizes (backproject_fast_eligible)
     const int tiles_x = (hr_cols + kUpdTileCols - 1) / kUpdTileCols, tiles_y = (hr_rows + kUpdTileRows - 1) / kUpdTileRows;
     hipLaunchKernelGGL(k_tile_relative, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, st, dec_fwd, hr_rows, hr_cols,
-                       tiles_x);
+                       tiles_x, (unsigned)dec_fwd_tile_words(hr_rows, hr_cols));
     return check_launch("tile_relative");
 }
 
