@@ -1637,6 +1637,10 @@ __global__ __launch_bounds__(64) void k_forward_sign_s2(const float* __restrict_
 // the lane at c0 = W reads columns W-4 .. W-1 and delivers column W-2 in the place of W.  The map entries and
 // the LR pixels of the next LR row are loaded before the pixels of the current one are gathered.
 constexpr int kFwd2Cols = 124;
+// the second gather of a lane whose four sources are not one run: by those lanes only (1) or by the whole wave (0)
+#ifndef SRX_S2W_LANEWISE
+#define SRX_S2W_LANEWISE 1
+#endif
 // SRX_FWD_S2_NARROW in the environment selects the one-column-per-lane kernel (for comparisons)
 static const bool g_forward_s2_wide = std::getenv("SRX_FWD_S2_NARROW") == nullptr;
 
@@ -1662,8 +1666,11 @@ template <int CH> struct __attribute__((packed, aligned(4))) YPair<CH, false>
     __device__ __forceinline__ float get(int j, int c) const { return v[CH * j + c]; }
 };
 
+#ifndef SRX_S2W_WAVES
+#define SRX_S2W_WAVES 5
+#endif
 template <int CH, bool Y8>
-__global__ __launch_bounds__(64) void k_forward_sign_s2w(const float* __restrict__ X, int H, int W, size_t ps,
+__global__ __launch_bounds__(64, SRX_S2W_WAVES) void k_forward_sign_s2w(const float* __restrict__ X, int H, int W, size_t ps,
                                                          PtrList bwd_maps, PtrList ys, MutPtrList signs, int K, GaussK g,
                                                          int strips_x, unsigned n_items)
 {
@@ -1714,7 +1721,7 @@ __global__ __launch_bounds__(64) void k_forward_sign_s2w(const float* __restrict
                 a[j][c] = v.v[j];
         }
         const bool ok1 = i[1] == i[0] + 1, ok2 = i[2] == i[0] + 2, ok3 = i[3] == i[0] + 3;
-        if (__builtin_amdgcn_ballot_w64(!(ok1 && ok2 && ok3)) != 0)
+        if (SRX_S2W_LANEWISE ? !(ok1 && ok2 && ok3) : __builtin_amdgcn_ballot_w64(!(ok1 && ok2 && ok3)) != 0)
         {
             const unsigned ib = max(i[3], 3u) - 3;
             const bool b1 = i[1] == ib + 1, b2 = i[2] == ib + 2, b3 = i[3] == ib + 3;
