@@ -226,6 +226,40 @@ def test_backproject_update(ops, rng, rows, cols, ch, scale, n, sigma, K, lam):
     assert np.array_equal(ref, got)
 
 
+@pytest.mark.parametrize("ch,lam", [(3, 0.03), (1, 0.0)])
+def test_backproject_update_scale_2_patches_that_fit_and_patches_that_do_not(ops, rng, ch, lam):
+    """Scale 2, several tiles of the update kernel per axis.  Per tile and frame the kernel stages the patch of
+    the sign plane that the tile's pixels reach in LDS when the patch is small enough, and gathers from global
+    memory otherwise; the frames here make tiles of both kinds, next to each other and in one window: smooth
+    motion, wild motion, smooth on the left and jittered on the right, and motion that leaves the image."""
+    rows, cols, scale, K = 40, 80, 2, 5
+    H, W = rows * scale, cols * scale
+    B, alpha, tau = 7, 0.7, 1.3
+    X = np.round(rng.random((H, W, ch)) * 255).astype(np.float32)
+    gk = oracle.gaussian_kernel(5, 0.0)
+    w = oracle.calc_btv_weights(B, alpha)
+    rels = [smooth_motion(rng, rows, cols, amp=2.5),
+            rng.standard_normal((rows, cols, 2)).astype(np.float32) * 12.0,
+            smooth_motion(rng, rows, cols, amp=1.5),
+            smooth_motion(rng, rows, cols, amp=1.0) + np.float32(9.0),
+            np.zeros((rows, cols, 2), np.float32)]
+    rels[2][:, cols // 2:] += rng.standard_normal((rows, cols - cols // 2, 2)).astype(np.float32) * 2.0
+    rels[3][:, :, 1] -= np.float32(14.0)
+    signs, fwd_floats, fwd_maps, signs_dev = [], [], [], []
+    for rel in rels[:K]:
+        hr = oracle.upscale_motion(rel, scale)
+        f, _ = oracle.build_motion_maps(hr)
+        s = rng.integers(-1, 2, (rows, cols, ch)).astype(np.float32)
+        signs.append(s)
+        fwd_floats.append(f)
+        fm, _ = ops.build_maps(dev(rel), scale)
+        fwd_maps.append(fm)
+        signs_dev.append(dev(ops.pack_signs(s)))
+    ref = _backproject_ref(X, signs, fwd_floats, scale, gk, B, w, tau, lam)
+    got = host(ops.backproject_update(dev(X), fwd_maps, signs_dev, scale, gk, B, w, tau, lam))
+    assert np.array_equal(ref, got)
+
+
 @pytest.mark.parametrize("ch,scale", [(1, 4), (3, 4), (3, 2)])
 def test_backproject_update_with_values_that_are_not_plain(ops, rng, ch, scale):
     """NaN, infinite, huge, denormal and signed-zero pixels: diffSign of the reference compares, so a NaN
