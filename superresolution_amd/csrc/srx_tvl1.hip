@@ -443,14 +443,14 @@ __device__ __forceinline__ void tvl1_u_values(float gx, float gy, float g, float
     n2 = v2 + theta * div2;
 }
 
-__global__ __launch_bounds__(256) void k_tvl1_iter4(Tvl1Planes P, int rows, int cols, float l_t, float theta,
+__global__ __launch_bounds__(32 * (kIt4Y + 2)) void k_tvl1_iter4(Tvl1Planes P, int rows, int cols, float l_t, float theta,
                                                      float taut, unsigned long long* __restrict__ err, int it,
                                                      unsigned long long thr)
 {
     if (it > 0 && err[it - 1] <= thr)
         return;
     __shared__ __attribute__((aligned(16))) float su1[(kIt4Y + 1) * kIt4Pitch], su2[(kIt4Y + 1) * kIt4Pitch];
-    __shared__ unsigned long long part[4];
+    __shared__ unsigned long long part[(kIt4Y + 2) / 2];
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 32 + tx;
     const int x0 = blockIdx.x * kIt4X, y0 = blockIdx.y * kIt4Y;
 
@@ -491,42 +491,34 @@ __global__ __launch_bounds__(256) void k_tvl1_iter4(Tvl1Planes P, int rows, int 
         return true;
     };
 
-    const int x = x0 + 4 * tx, y = y0 + ty;
+    // Rows 0 .. kIt4Y-1 of the block's threads own the tile's pixels; row kIt4Y works out the new u of the row
+    // below the tile and the first kIt4Y threads of row kIt4Y+1 that of the column right of it (four pixels each,
+    // the first is used), which the tile's last row and column need for their forward gradients.  Those two rows
+    // are a wave of their own: every wave makes one pass through new_u4 before the barrier.
+    const bool halo_row = ty == kIt4Y, halo_col = ty == kIt4Y + 1;
+    const int x = halo_col ? x0 + kIt4X : x0 + 4 * tx, y = halo_col ? y0 + tx : y0 + ty;
     float n1[4], n2[4], a[4], b[4];
     float4 q[4];
     unsigned long long e = 0;
-    const bool own = new_u4(x, y, n1, n2, a, b, q);
+    const bool have = !(halo_col && tx >= kIt4Y) && new_u4(x, y, n1, n2, a, b, q);
+    const bool own = have && ty < kIt4Y;
     if (own)
     {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             e += error_term(n1[k] - a[k], n2[k] - b[k]);
+    }
+    if (have && !halo_col)
+    {
         *(float4*)&su1[ty * kIt4Pitch + 4 * tx] = make_float4(n1[0], n1[1], n1[2], n1[3]);
         *(float4*)&su2[ty * kIt4Pitch + 4 * tx] = make_float4(n2[0], n2[1], n2[2], n2[3]);
     }
-    // the row below the tile (threads 0..31, four pixels each) and the column right of it (threads 32..39)
-    if (tid < 32)
+    else if (have)
     {
-        float h1[4], h2[4], ha[4], hb[4];
-        float4 hq[4];
-        if (new_u4(x0 + 4 * tid, y0 + kIt4Y, h1, h2, ha, hb, hq))
-        {
-            *(float4*)&su1[kIt4Y * kIt4Pitch + 4 * tid] = make_float4(h1[0], h1[1], h1[2], h1[3]);
-            *(float4*)&su2[kIt4Y * kIt4Pitch + 4 * tid] = make_float4(h2[0], h2[1], h2[2], h2[3]);
-        }
+        su1[tx * kIt4Pitch + kIt4X] = n1[0];
+        su2[tx * kIt4Pitch + kIt4X] = n2[0];
     }
-    else if (tid < 32 + kIt4Y)
-    {
-        const int hx = x0 + kIt4X, hy = y0 + (tid - 32);
-        if (hx < cols && hy < rows)
-        {
-            Tvl1Planes Q = P;
-            float h1, h2, ha, hb;
-            tvl1_new_u(Q, hx, hy, cols, l_t, theta, h1, h2, ha, hb);
-            su1[(tid - 32) * kIt4Pitch + kIt4X] = h1;
-            su2[(tid - 32) * kIt4Pitch + kIt4X] = h2;
-        }
-    }
+    (void)halo_row;
     __syncthreads();
     if (own)
     {
@@ -564,6 +556,7 @@ __global__ __launch_bounds__(256) void k_tvl1_iter4(Tvl1Planes P, int rows, int 
     __syncthreads();
     if (tid == 0)
         atomicAdd(&err[it], part[0] + part[1] + part[2] + part[3]);
+    static_assert(kIt4Y == 8, "four waves own pixels");
 }
 
 // Several inner iterations in one launch.  A block owns a tile of TW x TH pixels and loads it with a halo of
@@ -999,7 +992,7 @@ int Tvl1::calc_gray(const float* I0, const float* I1, int rows, int cols, const 
                 if (size_class == 2) // one iteration per launch: launch `bidx` is iteration `bidx`
                 {
                     if (C % 4 == 0)
-                        hipLaunchKernelGGL(k_tvl1_iter4, grid2(C, R, dim3(kIt4X, kIt4Y)), dim3(32, kIt4Y), 0, st, P, R, C,
+                        hipLaunchKernelGGL(k_tvl1_iter4, grid2(C, R, dim3(kIt4X, kIt4Y)), dim3(32, kIt4Y + 2), 0, st, P, R, C,
                                            l_t, theta, taut, m.err.as<unsigned long long>(), bidx, thr);
                     else
                         hipLaunchKernelGGL(k_tvl1_iter, grid2(C, R, dim3(kItX, kItY)), dim3(kItX, kItY), 0, st, P, R, C,
