@@ -410,8 +410,13 @@ __global__ __launch_bounds__(256) void k_tvl1_iter(Tvl1Planes P, int rows, int c
 
 // The same iteration with four pixels of a row per thread and 16-byte accesses, for levels whose
 // width is a multiple of 4 (every plane is then 16-byte aligned row by row).  A block covers
-// 128 x 8 pixels.  Values per pixel are computed exactly as in k_tvl1_iter.
-constexpr int kIt4X = 128, kIt4Y = 8, kIt4Pitch = kIt4X + 4;
+// 128 x kIt4Y pixels.  Values per pixel are computed exactly as in k_tvl1_iter.
+// rows of a tile (even; 12 measured best of 8 .. 30 at 1920x1080: the halo row is a twelfth of the loads, and
+// 1080, 540 and 270 rows are whole numbers of tiles)
+#ifndef SRX_IT4_ROWS
+#define SRX_IT4_ROWS 12
+#endif
+constexpr int kIt4X = 128, kIt4Y = SRX_IT4_ROWS, kIt4Pitch = kIt4X + 4;
 
 __device__ __forceinline__ void tvl1_u_values(float gx, float gy, float g, float rc, float a, float b, float q11,
                                               float q12, float q21, float q22, float left11, float left21, float up12,
@@ -555,8 +560,14 @@ __global__ __launch_bounds__(32 * (kIt4Y + 2)) void k_tvl1_iter4(Tvl1Planes P, i
         part[tid >> 6] = e;
     __syncthreads();
     if (tid == 0)
-        atomicAdd(&err[it], part[0] + part[1] + part[2] + part[3]);
-    static_assert(kIt4Y == 8, "four waves own pixels");
+    {
+        unsigned long long sum = 0;
+#pragma unroll
+        for (int wv = 0; wv < kIt4Y / 2; ++wv) // the waves that own pixels
+            sum += part[wv];
+        atomicAdd(&err[it], sum);
+    }
+    static_assert(kIt4Y % 2 == 0, "whole waves own pixels");
 }
 
 // Several inner iterations in one launch.  A block owns a tile of TW x TH pixels and loads it with a halo of
