@@ -1637,10 +1637,6 @@ __global__ __launch_bounds__(64) void k_forward_sign_s2(const float* __restrict_
 // the lane at c0 = W reads columns W-4 .. W-1 and delivers column W-2 in the place of W.  The map entries and
 // the LR pixels of the next LR row are loaded before the pixels of the current one are gathered.
 constexpr int kFwd2Cols = 124;
-// the second gather of a lane whose four sources are not one run: by those lanes only (1) or by the whole wave (0)
-#ifndef SRX_S2W_LANEWISE
-#define SRX_S2W_LANEWISE 1
-#endif
 // SRX_FWD_S2_NARROW in the environment selects the one-column-per-lane kernel (for comparisons)
 static const bool g_forward_s2_wide = std::getenv("SRX_FWD_S2_NARROW") == nullptr;
 
@@ -1667,7 +1663,7 @@ template <int CH> struct __attribute__((packed, aligned(4))) YPair<CH, false>
 };
 
 #ifndef SRX_S2W_WAVES
-#define SRX_S2W_WAVES 5
+#define SRX_S2W_WAVES 4
 #endif
 template <int CH, bool Y8>
 __global__ __launch_bounds__(64, SRX_S2W_WAVES) void k_forward_sign_s2w(const float* __restrict__ X, int H, int W, size_t ps,
@@ -1700,55 +1696,69 @@ __global__ __launch_bounds__(64, SRX_S2W_WAVES) void k_forward_sign_s2w(const fl
     const int row_quads = W >> 2;
 
     auto entries = [&](int Y) { return stream_load(map + (size_t)reflect101(Y, H) * row_quads); };
-    // row pass of an HR row from the lane's four map entries: out[0] for LR column xa, out[1] for xa + 1
-    auto hr_row = [&](const uint4 e, float (&out)[2][CH]) {
-        const uint32_t ev[4] = {e.x, e.y, e.z, e.w};
+    // An HR row in two steps, so that the gathers of the two HR rows of an LR row are all in flight before the
+    // first of them is waited for: gathers from the lane's four map entries, then the row pass: out[0] for LR
+    // column xa, out[1] for xa + 1.
+    struct Row
+    {
         unsigned i[4];
+        bool ok1, ok2, ok3, b1, b2, b3;
+        packed_floats<4> v[CH], t[CH];
+    };
+    auto hr_issue = [&](const uint4 e, Row& r) {
+        const uint32_t ev[4] = {e.x, e.y, e.z, e.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
         {
             const int mx = (int)(short)(ev[j] & 0xFFFF), my = (int)ev[j] >> 16;
             const bool in = (unsigned)mx < (unsigned)W && (unsigned)my < (unsigned)H;
-            i[j] = in ? (unsigned)(my * W + mx) : zero_px + j;
+            r.i[j] = in ? (unsigned)(my * W + mx) : zero_px + j;
         }
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            r.v[c] = *(const packed_floats<4>*)(X + c * ps + r.i[0]);
+        r.ok1 = r.i[1] == r.i[0] + 1, r.ok2 = r.i[2] == r.i[0] + 2, r.ok3 = r.i[3] == r.i[0] + 3;
+        // the second gather, which ends at the fourth source, by the lanes whose sources are not one run
+        const unsigned ib = max(r.i[3], 3u) - 3;
+        r.b1 = r.i[1] == ib + 1, r.b2 = r.i[2] == ib + 2, r.b3 = r.i[3] == ib + 3;
+        if (!(r.ok1 && r.ok2 && r.ok3))
+        {
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                r.t[c] = *(const packed_floats<4>*)(X + c * ps + ib);
+        }
+    };
+    auto hr_finish = [&](Row& r, float (&out)[2][CH]) {
         float a[4][CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c)
-        {
-            const packed_floats<4> v = *(const packed_floats<4>*)(X + c * ps + i[0]);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                a[j][c] = v.v[j];
-        }
-        const bool ok1 = i[1] == i[0] + 1, ok2 = i[2] == i[0] + 2, ok3 = i[3] == i[0] + 3;
-        if (SRX_S2W_LANEWISE ? !(ok1 && ok2 && ok3) : __builtin_amdgcn_ballot_w64(!(ok1 && ok2 && ok3)) != 0)
+                a[j][c] = r.v[c].v[j];
+        if (!(r.ok1 && r.ok2 && r.ok3))
         {
-            const unsigned ib = max(i[3], 3u) - 3;
-            const bool b1 = i[1] == ib + 1, b2 = i[2] == ib + 2, b3 = i[3] == ib + 3;
 #pragma unroll
             for (int c = 0; c < CH; ++c)
             {
-                packed_floats<4> v = *(const packed_floats<4>*)(X + c * ps + ib);
-                asm volatile("" : "+v"(v.v[1]), "+v"(v.v[2]), "+v"(v.v[3])); // one 16-byte load, not a load per condition
-                a[1][c] = ok1 ? a[1][c] : v.v[1];
-                a[2][c] = ok2 ? a[2][c] : v.v[2];
-                a[3][c] = ok3 ? a[3][c] : v.v[3];
+                a[1][c] = r.ok1 ? a[1][c] : r.t[c].v[1];
+                a[2][c] = r.ok2 ? a[2][c] : r.t[c].v[2];
+                a[3][c] = r.ok3 ? a[3][c] : r.t[c].v[3];
             }
-            if (__builtin_amdgcn_ballot_w64(!((ok1 || b1) && (ok2 || b2) && (ok3 || b3))) != 0)
-            {
-                if (!(ok1 || b1))
+        }
+        if (__builtin_amdgcn_ballot_w64(!((r.ok1 || r.b1) && (r.ok2 || r.b2) && (r.ok3 || r.b3))) != 0)
+        {
+            if (!(r.ok1 || r.b1))
 #pragma unroll
-                    for (int c = 0; c < CH; ++c)
-                        a[1][c] = X[c * ps + i[1]];
-                if (!(ok2 || b2))
+                for (int c = 0; c < CH; ++c)
+                    a[1][c] = X[c * ps + r.i[1]];
+            if (!(r.ok2 || r.b2))
 #pragma unroll
-                    for (int c = 0; c < CH; ++c)
-                        a[2][c] = X[c * ps + i[2]];
-                if (!(ok3 || b3))
+                for (int c = 0; c < CH; ++c)
+                    a[2][c] = X[c * ps + r.i[2]];
+            if (!(r.ok3 || r.b3))
 #pragma unroll
-                    for (int c = 0; c < CH; ++c)
-                        a[3][c] = X[c * ps + i[3]];
-            }
+                for (int c = 0; c < CH; ++c)
+                    a[3][c] = X[c * ps + r.i[3]];
         }
 #pragma unroll
         for (int c = 0; c < CH; ++c)
@@ -1766,6 +1776,11 @@ __global__ __launch_bounds__(64, SRX_S2W_WAVES) void k_forward_sign_s2w(const fl
             out[1][c] = sum;
         }
     };
+    auto hr_row = [&](const uint4 e, float (&out)[2][CH]) {
+        Row r;
+        hr_issue(e, r);
+        hr_finish(r, out);
+    };
 
     float rr[5][2][CH];
     hr_row(entries(2 * y0 - 2), rr[0]);
@@ -1778,8 +1793,13 @@ __global__ __launch_bounds__(64, SRX_S2W_WAVES) void k_forward_sign_s2w(const fl
         const int yn = min(y + 1, h - 1);
         const uint4 n3 = entries(2 * yn + 1), n4 = entries(2 * yn + 2);
         const y_pair ynext = *(const y_pair*)(yk + (size_t)yn * w * CH);
-        hr_row(e3, rr[3]);
-        hr_row(e4, rr[4]);
+        {
+            Row ra, rb;
+            hr_issue(e3, ra);
+            hr_issue(e4, rb);
+            hr_finish(ra, rr[3]);
+            hr_finish(rb, rr[4]);
+        }
         uint32_t sg[2] = {0, 0};
 #pragma unroll
         for (int j = 0; j < 2; ++j)
