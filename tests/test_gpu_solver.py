@@ -70,6 +70,9 @@ CASES = [
     (3, 10, 130, 3, 1, dict(iterations=4, scale=2)),
     (3, 12, 66, 1, 1, dict(iterations=4, scale=2)),
     (3, 12, 65, 1, 1, dict(iterations=4, scale=2)),
+    # scale 2 over several tiles of the update kernel in both directions (sign patches staged per tile and frame)
+    (5, 48, 80, 3, 2, dict(iterations=6, scale=2)),
+    (4, 40, 72, 1, 3, dict(iterations=5, scale=2, lambda_=0.0)),
     # more window frames than one block of the scale-4 forward kernel takes (two passes over the tile),
     # and a strip boundary (more than 63 LR columns)
     (11, 12, 70, 3, 5, dict(iterations=3)),
