@@ -18,19 +18,27 @@
 //    for bit against the restatement of lib/src/btv_l1.cpp; with the built-in flows the motions differ from
 //    OpenCV's in the last bits (Farneback and TV-L1 are restated from their published algorithms), so expect
 //    agreement to a few hundredths of a dB, not to the digit.
+//  * the low-resolution frames without noise: cv::GaussianBlur on 8-bit data (main.cpp:130-131) runs in fixed
+//    point - kernel {1,4,6,4,1}/16 times 256 per pass, result (sum + 2^15) >> 16, i.e. the exact sum rounded half
+//    up - and so does the blur here; INTER_NEAREST takes every scale-th pixel;
+//  * the BiCubic column: cv::resize on 8-bit data (main.cpp:318) works with coefficients rounded to 11 bits and
+//    integer sums, result (sum + 2^21) >> 22 saturated; restated here from OpenCV 2.4's resize (coefficients of
+//    a = -0.75 in float, times 2048, rounded to nearest even; columns whose second tap falls outside the image
+//    become plain copies, taps clipped to the image otherwise).
+// Restated from the OpenCV 2.4 sources as the written spec, like the solver's OpenCV routines: nothing here was
+// checked against a run of OpenCV (it is not installed), so "can be compared" means "is meant to agree".
 // What cannot match to the digit:
-//  * the low-resolution frames themselves: the reference degrades with cv::GaussianBlur on 8-bit data
-//    (main.cpp:130-131), which runs in fixed point; the blur here runs in float and rounds once;
-//  * the BiCubic column: cv::resize on 8-bit data (main.cpp:318) uses 11-bit fixed-point coefficients; here the
-//    enlargement is computed in float and rounded.
+//  * frames with --noise: the reference draws from cv::theRNG(), the harness from its own seeded generator.
 #include <srx/superres.hpp>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <random>
 #include <string>
+#include <vector>
 
 using namespace srx;
 
@@ -95,13 +103,15 @@ class DegradedSource : public IFrameSource
         if (f.empty())
             return f;
         const int R = f.rows(), C = f.cols(), ch = f.channels();
-        static const float k[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
-        std::vector<float> tmp((size_t)R * C * ch), blur((size_t)R * C * ch);
+        // cv::GaussianBlur(8U, Size(5, 5), 0): both passes in integers with the kernel times 256
+        static const int k[5] = {16, 64, 96, 64, 16};
+        std::vector<int> tmp((size_t)R * C * ch);
+        std::vector<uint8_t> blur((size_t)R * C * ch);
         for (int y = 0; y < R; ++y)
             for (int x = 0; x < C; ++x)
                 for (int c = 0; c < ch; ++c)
                 {
-                    float s = 0;
+                    int s = 0;
                     for (int j = -2; j <= 2; ++j)
                         s += k[j + 2] * f.ptr<uint8_t>(y)[reflect101(x + j, C) * ch + c];
                     tmp[((size_t)y * C + x) * ch + c] = s;
@@ -109,10 +119,10 @@ class DegradedSource : public IFrameSource
         for (int y = 0; y < R; ++y)
             for (int x = 0; x < C * ch; ++x)
             {
-                float s = 0;
+                int s = 0;
                 for (int j = -2; j <= 2; ++j)
                     s += k[j + 2] * tmp[(size_t)reflect101(y + j, R) * C * ch + x];
-                blur[(size_t)y * C * ch + x] = s;
+                blur[(size_t)y * C * ch + x] = (uint8_t)((s + (1 << 15)) >> 16);
             }
         Mat d(R / scale_, C / scale_, ch, SRX_8U);
         std::normal_distribution<float> gauss(0.f, 10.f);
@@ -123,7 +133,7 @@ class DegradedSource : public IFrameSource
                 const bool hit = noise_ && spike(rng_) < 1;
                 for (int c = 0; c < ch; ++c)
                 {
-                    float v = std::nearbyint(blur[((size_t)y * scale_ * C + (size_t)x * scale_) * ch + c]);
+                    float v = (float)blur[((size_t)y * scale_ * C + (size_t)x * scale_) * ch + c];
                     if (noise_)
                         v = std::nearbyint(v + gauss(rng_));
                     v = hit ? 255.f : std::fmin(std::fmax(v, 0.f), 255.f);
@@ -140,45 +150,67 @@ class DegradedSource : public IFrameSource
     std::mt19937 rng_{1234};
 };
 
-// cubic enlargement in float (a = -0.75, taps clamped to the image), rounded to 8 bits
+// cv::resize(8U, INTER_CUBIC) by an integer factor: coefficients of a = -0.75 rounded to 11 bits, integer sums
+short cubic_coeff_11(float v)
+{
+    const float r = std::nearbyint(v * 2048.0f); // cvRound: to nearest, ties to even
+    return (short)std::fmin(std::fmax(r, -32768.f), 32767.f);
+}
+void cubic_table(int ssize, int dsize, bool snap, std::vector<int>& ofs, std::vector<short>& coef)
+{
+    ofs.resize(dsize), coef.resize(4 * (size_t)dsize);
+    const double scale = 1.0 / ((double)dsize / ssize);
+    for (int d = 0; d < dsize; ++d)
+    {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int sp = (int)std::floor(f);
+        f -= sp;
+        if (snap) // columns: a second tap left of the image or on / behind its last column makes a plain copy
+        {
+            if (sp < 0)
+                f = 0, sp = 0;
+            if (sp >= ssize - 1)
+                f = 0, sp = ssize - 1;
+        }
+        const float A = -0.75f;
+        float c[4];
+        c[0] = ((A * (f + 1) - 5 * A) * (f + 1) + 8 * A) * (f + 1) - 4 * A;
+        c[1] = ((A + 2) * f - (A + 3)) * f * f + 1;
+        c[2] = ((A + 2) * (1 - f) - (A + 3)) * (1 - f) * (1 - f) + 1;
+        c[3] = 1.f - c[0] - c[1] - c[2];
+        ofs[d] = sp;
+        for (int i = 0; i < 4; ++i)
+            coef[4 * (size_t)d + i] = cubic_coeff_11(c[i]);
+    }
+}
 Mat bicubic(const Mat& src, int scale)
 {
-    const int R = src.rows() * scale, C = src.cols() * scale, ch = src.channels();
+    const int sr = src.rows(), sc = src.cols(), R = sr * scale, C = sc * scale, ch = src.channels();
     Mat dst(R, C, ch, SRX_8U);
-    auto w = [](float t, float* o) {
-        const float A = -0.75f;
-        o[0] = ((A * (t + 1) - 5 * A) * (t + 1) + 8 * A) * (t + 1) - 4 * A;
-        o[1] = ((A + 2) * t - (A + 3)) * t * t + 1;
-        o[2] = ((A + 2) * (1 - t) - (A + 3)) * (1 - t) * (1 - t) + 1;
-        o[3] = 1.f - o[0] - o[1] - o[2];
-    };
-    for (int y = 0; y < R; ++y)
-    {
-        const float fy = (y + 0.5f) / scale - 0.5f;
-        const int sy = (int)std::floor(fy);
-        float wy[4];
-        w(fy - sy, wy);
+    std::vector<int> xofs, yofs;
+    std::vector<short> alpha, beta;
+    cubic_table(sc, C, true, xofs, alpha);
+    cubic_table(sr, R, false, yofs, beta);
+    // every source row to the destination width
+    std::vector<int> hres((size_t)sr * C * ch);
+    for (int y = 0; y < sr; ++y)
         for (int x = 0; x < C; ++x)
-        {
-            const float fx = (x + 0.5f) / scale - 0.5f;
-            const int sx = (int)std::floor(fx);
-            float wx[4];
-            w(fx - sx, wx);
             for (int c = 0; c < ch; ++c)
             {
-                float s = 0;
-                for (int j = 0; j < 4; ++j)
-                {
-                    const int yy = std::min(std::max(sy - 1 + j, 0), src.rows() - 1);
-                    float r = 0;
-                    for (int i = 0; i < 4; ++i)
-                        r += wx[i] * src.ptr<uint8_t>(yy)[std::min(std::max(sx - 1 + i, 0), src.cols() - 1) * ch + c];
-                    s += wy[j] * r;
-                }
-                dst.ptr<uint8_t>(y)[x * ch + c] = (uint8_t)std::fmin(std::fmax(std::nearbyint(s), 0.f), 255.f);
+                int s = 0;
+                for (int i = 0; i < 4; ++i)
+                    s += alpha[4 * (size_t)x + i] * src.ptr<uint8_t>(y)[std::min(std::max(xofs[x] - 1 + i, 0), sc - 1) * ch + c];
+                hres[((size_t)y * C + x) * ch + c] = s;
             }
+    for (int y = 0; y < R; ++y)
+        for (int x = 0; x < C * ch; ++x)
+        {
+            int s = 0;
+            for (int j = 0; j < 4; ++j)
+                s += beta[4 * (size_t)y + j] * hres[(size_t)std::min(std::max(yofs[y] - 1 + j, 0), sr - 1) * C * ch + x];
+            const int v = (s + (1 << 21)) >> 22;
+            dst.ptr<uint8_t>(y)[x] = (uint8_t)std::min(std::max(v, 0), 255);
         }
-    }
     return dst;
 }
 
@@ -207,8 +239,88 @@ bool arg_flag(int argc, char** argv, const char* name)
 
 } // namespace
 
+// --selftest: the host-side image routines against straightforward double-precision statements (no GPU involved)
+int selftest()
+{
+    std::mt19937 rng(99);
+    int bad = 0;
+    for (int ch = 1; ch <= 3; ch += 2)
+    {
+        const int rows = 13, cols = 18, scale = 4;
+        Mat img(rows, cols, ch, SRX_8U);
+        for (int y = 0; y < rows; ++y)
+            for (int x = 0; x < cols * ch; ++x)
+                img.ptr<uint8_t>(y)[x] = (uint8_t)(rng() & 255);
+        // bicubic: the fixed-point result is within one grey level of the same taps in double precision
+        const Mat up = bicubic(img, scale);
+        std::vector<int> xo, yo;
+        std::vector<short> a, b;
+        cubic_table(cols, cols * scale, true, xo, a);
+        cubic_table(rows, rows * scale, false, yo, b);
+        for (int y = 0; y < rows * scale; ++y)
+            for (int x = 0; x < cols * scale; ++x)
+                for (int c = 0; c < ch; ++c)
+                {
+                    double s = 0;
+                    for (int j = 0; j < 4; ++j)
+                        for (int i = 0; i < 4; ++i)
+                            s += (b[4 * (size_t)y + j] / 2048.0) * (a[4 * (size_t)x + i] / 2048.0) *
+                                 img.ptr<uint8_t>(std::min(std::max(yo[y] - 1 + j, 0), rows - 1))[std::min(std::max(xo[x] - 1 + i, 0), cols - 1) * ch + c];
+                    const double want = std::fmin(std::fmax(std::floor(s + 0.5), 0.0), 255.0);
+                    if (std::fabs(want - up.ptr<uint8_t>(y)[x * ch + c]) > 0.0)
+                        ++bad;
+                }
+        // an image enlarged from a constant one stays within one level of it (the rounded coefficients need not add up to 2048)
+        Mat flat(rows, cols, ch, SRX_8U);
+        for (int y = 0; y < rows; ++y)
+            std::memset(flat.ptr<uint8_t>(y), 200, (size_t)cols * ch);
+        const Mat fu = bicubic(flat, scale);
+        for (int y = 0; y < rows * scale; ++y)
+            for (int x = 0; x < cols * scale * ch; ++x)
+                if (std::abs((int)fu.ptr<uint8_t>(y)[x] - 200) > 1)
+                    ++bad;
+    }
+    // degrade: exact sums of the 5x5 {1,4,6,4,1}/16 kernel rounded half up, then every scale-th pixel
+    struct OneFrame : IFrameSource
+    {
+        Mat m;
+        bool given = false;
+        void reset() override { given = false; }
+        Mat nextFrame() override
+        {
+            if (given)
+                return Mat();
+            given = true;
+            return m;
+        }
+    };
+    OneFrame* one = new OneFrame;
+    one->m = Mat(12, 16, 1, SRX_8U);
+    for (int y = 0; y < 12; ++y)
+        for (int x = 0; x < 16; ++x)
+            one->m.ptr<uint8_t>(y)[x] = (uint8_t)(rng() & 255);
+    // two pixels arranged so that the exact sum of a window ends in .5: 255/256 * 128 ... checked below through the general rule
+    DegradedSource deg(Ptr<IFrameSource>(one), 2, false);
+    const Mat d = deg.nextFrame();
+    static const double k[5] = {1 / 16.0, 4 / 16.0, 6 / 16.0, 4 / 16.0, 1 / 16.0};
+    for (int y = 0; y < d.rows(); ++y)
+        for (int x = 0; x < d.cols(); ++x)
+        {
+            double s = 0;
+            for (int j = -2; j <= 2; ++j)
+                for (int i = -2; i <= 2; ++i)
+                    s += k[j + 2] * k[i + 2] * one->m.ptr<uint8_t>(reflect101(2 * y + j, 12))[reflect101(2 * x + i, 16)];
+            if ((int)std::floor(s + 0.5) != d.ptr<uint8_t>(y)[x])
+                ++bad;
+        }
+    std::printf("selftest: %s (%d mismatches)\n", bad ? "FAILED" : "ok", bad);
+    return bad ? 1 : 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (arg_flag(argc, argv, "--selftest"))
+        return selftest();
     const int scale = arg_int(argc, argv, "--scale", 4), iterations = arg_int(argc, argv, "--iterations", 180);
     const int temporal = arg_int(argc, argv, "--temporal", 4);
     const int rows = arg_int(argc, argv, "--rows", 240) / scale * scale, cols = arg_int(argc, argv, "--cols", 320) / scale * scale;

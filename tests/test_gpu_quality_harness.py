@@ -25,3 +25,14 @@ def test_super_resolution_beats_bicubic(channels, flow):
     sr = sum(float(x[1]) for x in rows) / len(rows)
     bc = sum(float(x[3]) for x in rows) / len(rows)
     assert sr > bc + 1.0, r.stdout            # at least 1 dB over bicubic on this clip
+
+
+def test_host_side_image_routines_of_the_harness():
+    """The harness restates cv::GaussianBlur and cv::resize(INTER_CUBIC) on 8-bit data in fixed point
+    (samples/quality_test/main.cpp:130-131, 318); its --selftest compares them with double-precision statements
+    of the same sums: the blur exactly (rounded half up), the enlargement exactly given the 11-bit coefficients,
+    a constant image within one grey level.  No GPU involved."""
+    if not os.path.exists(EXE):  # built by __graft_entry__.build(); a tree that only ran `make` in csrc/ builds it here
+        subprocess.run(["make", "-C", os.path.join(ROOT, "samples")], check=True, capture_output=True, timeout=300)
+    r = subprocess.run([EXE, "--selftest"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "selftest: ok" in r.stdout, r.stdout + r.stderr
