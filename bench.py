@@ -494,6 +494,17 @@ def bench_tvl1(args):
     elapsed = R.max_over_ranks(time.perf_counter() - t0)
     if R.rank == 0:
         bytes_pair = 64.0 * float(np.mean(work))  # 16 floats read or written per pixel and inner iteration
+        # HBM-side bytes per pair of all flow kernels from the committed PMC passes (scripts/pmc_tvl1.sh), 1080p only
+        pair_traffic = pair_traffic_src = None
+        if (rows, cols) == (1080, 1920):
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_tvl1_traffic.json")))
+            try:
+                if files:
+                    pair_traffic = json.load(open(files[-1]))["traffic_bytes_per_pair"]
+                    pair_traffic_src = os.path.relpath(files[-1], ROOT)
+            except (OSError, ValueError, KeyError):
+                pass
         per_pair_s = elapsed / args.steps
         line = {
             "metric": f"TV-L1 flow stage, {cols}x{rows} grey frame pairs per second",
@@ -520,8 +531,8 @@ def bench_tvl1(args):
                 "bound": "hbm", "kernel": "k_tvl1_iter4 on levels of a megapixel and more (one inner iteration per launch), "
                                            "k_tvl1_multi below (4 or 8 inner iterations per launch)",
                 "achieved": bytes_pair / per_pair_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": bytes_pair / per_pair_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                "algorithmic_bytes_per_pair": bytes_pair,
+                "frac": bytes_pair / per_pair_s / 1e9 / HBM_PEAK_GBS, "traffic": pair_traffic,
+                "traffic_source": pair_traffic_src, "algorithmic_bytes_per_pair": bytes_pair,
                 "what": "64 B x executed pixel-iterations over the whole pair time (pyramid, warps, gradient passes "
                         "and the host's convergence polling included)"},
         }
