@@ -2041,18 +2041,15 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B3_WAV
             for (int it = 0; it < NIT1; ++it)
             {
                 const int idx = tid + it * kThreads;
-                const int r = idx / RV, c4 = idx - r * RV;
-                const int gi = i0 - HALO + r, gj = j0 - HL + 4 * c4;
-                // W and gj are multiples of 4: a chunk is entirely inside or outside the row
-                const bool in = gi >= 0 && gi < H && gj >= 0 && gj < W;
                 if (idx < NCH1)
                 {
                     const float4 v = stage[it];
                     const v2f lo = v2f{btv_tile_value(v.x), btv_tile_value(v.y)}, hi = v2f{btv_tile_value(v.z), btv_tile_value(v.w)};
                     weird = __builtin_elementwise_fma(lo, v2f{0.0f, 0.0f}, weird);
                     weird = __builtin_elementwise_fma(hi, v2f{0.0f, 0.0f}, weird);
-                    // outside the image the tile holds 0; those cells are never read by an interior pixel
-                    *(float4*)&tile[4 * idx] = in ? make_float4(lo.x, lo.y, hi.x, hi.y) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    // cells outside the image hold copies of edge pixels (the loads are clamped); only pixels
+                    // within HALO of the image edge read them, and their regulariser is discarded below
+                    *(float4*)&tile[4 * idx] = make_float4(lo.x, lo.y, hi.x, hi.y);
                 }
             }
             {
