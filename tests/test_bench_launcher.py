@@ -47,3 +47,20 @@ def test_a_failing_rank_fails_the_launcher():
     p = _run(["--gpus", "2", "--workload", "tvl1"], SRX_BENCH_REHEARSE="dry")
     assert p.returncode != 0
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_measured_traffic_is_looked_up_per_workload():
+    """The roofline objects quote HBM traffic from the committed counter passes: the headline workload from
+    profiles/rNN_traffic.json, the scale-2 configuration from profiles/rNN_cfg5_traffic.json; a kernel or a
+    workload without a pass has none."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t4, src4 = bench.measured_traffic("k_backproject_update_s4")
+    t5, src5 = bench.measured_traffic("k_backproject_update_s4", "cfg5")
+    assert t4 and src4.endswith("_traffic.json") and "cfg5" not in src4 and "tvl1" not in src4
+    assert t5 and src5.endswith("_cfg5_traffic.json") and t5 != t4
+    assert bench.measured_traffic("k_no_such_kernel", "cfg5") == (None, None)
+    assert bench.measured_traffic("k_backproject_update_s4", "no_such_workload") == (None, None)
