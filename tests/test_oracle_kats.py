@@ -306,3 +306,54 @@ def test_streaming_driver_counts():
     o2.setFrameSource(ostream.ListFrameSource(frames[:5]))
     with pytest.raises(RuntimeError):
         o2.nextFrame()
+
+
+# --- third-party second opinions ---------------------------------------------------------------------------
+# Code by other authors that implements the same published rules: they do not pin parity with the reference
+# (neither is OpenCV), they catch a rule of OpenCV's that was remembered wrongly when the oracle was written.
+# Compared at a tolerance, away from the places where the libraries are known to treat borders differently.
+def test_third_party_bicubic_of_torch_agrees_inside_the_image(rng):
+    """torch.nn.functional.interpolate(mode="bicubic", align_corners=False): the same kernel (a = -0.75), the same
+    pixel-centre mapping and taps clamped to the image; OpenCV 2.4 turns columns whose second tap leaves the image
+    into plain copies, so the outermost two source columns are left out of the comparison."""
+    torch = pytest.importorskip("torch")
+    for s in (2, 4):
+        src = (rng.random((13, 17)) * 255).astype(np.float32)
+        ours = oracle.resize_cubic(src[:, :, None], 13 * s, 17 * s)[:, :, 0]
+        theirs = torch.nn.functional.interpolate(torch.from_numpy(src)[None, None], scale_factor=s, mode="bicubic",
+                                                 align_corners=False)[0, 0].numpy()
+        inner = slice(2 * s, -2 * s)
+        assert np.abs(ours[:, inner] - theirs[:, inner]).max() < 2e-3  # values up to 255 (and overshoot), float32 sums
+
+
+def test_third_party_mirror_correlation_of_scipy_agrees(rng):
+    """scipy.ndimage.correlate1d(mode="mirror") is BORDER_REFLECT_101; two passes of it are the separable filter."""
+    ndi = pytest.importorskip("scipy.ndimage")
+    src = (rng.random((19, 23, 3)) * 255).astype(np.float32)
+    for n, sigma in ((5, 0.0), (7, 1.7), (3, 0.0)):
+        k = oracle.gaussian_kernel(n, sigma)
+        ours = oracle.sep_filter(src, k)
+        t = ndi.correlate1d(src.astype(np.float64), k.astype(np.float64), axis=1, mode="mirror")
+        theirs = ndi.correlate1d(t, k.astype(np.float64), axis=0, mode="mirror")
+        assert np.abs(ours - theirs).max() < 1e-3
+
+
+def test_third_party_gaussian_window_of_scipy_agrees():
+    """cv::getGaussianKernel for sigma > 0 is the sampled Gaussian normalised to sum 1, as scipy.signal.windows.gaussian
+    divided by its sum; for sigma <= 0 and sizes up to 7 OpenCV uses fixed tables (binomial for 3 and 5)."""
+    win = pytest.importorskip("scipy.signal.windows")
+    for n, sigma in ((5, 1.3), (7, 2.0), (9, 1.1)):
+        g = win.gaussian(n, sigma)
+        assert np.abs(oracle.gaussian_kernel(n, sigma) - g / g.sum()).max() < 1e-6
+    assert np.array_equal(oracle.gaussian_kernel(5, 0.0), np.array([1, 4, 6, 4, 1], np.float32) / 16)
+    assert np.array_equal(oracle.gaussian_kernel(3, 0.0), np.array([1, 2, 1], np.float32) / 4)
+
+
+def test_third_party_rounding_of_numpy_agrees(rng):
+    """cvRound on the map coordinates is round-half-to-even, as numpy.rint; saturate_cast<short> clips."""
+    m = np.concatenate([rng.random(500).astype(np.float32) * 80 - 40, np.arange(-20, 20, dtype=np.float32) + 0.5,
+                        np.array([1e9, -1e9, 32767.4, -32768.6], np.float32)])
+    fmap = np.stack([m, m[::-1]], -1).reshape(1, -1, 2).copy()
+    ours = oracle.map_to_short(fmap)
+    theirs = np.clip(np.rint(fmap.astype(np.float64)), -32768, 32767).astype(np.int16)
+    assert np.array_equal(ours, theirs)
