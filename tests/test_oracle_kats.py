@@ -357,3 +357,19 @@ def test_third_party_rounding_of_numpy_agrees(rng):
     ours = oracle.map_to_short(fmap)
     theirs = np.clip(np.rint(fmap.astype(np.float64)), -32768, 32767).astype(np.int16)
     assert np.array_equal(ours, theirs)
+
+
+def test_third_party_numpy_statements_of_the_simple_steps(rng):
+    """convertTo(CV_8U) is round-half-even with saturation, addWeighted sums in double and rounds once to float,
+    cv::resize(INTER_NEAREST) by 1/s takes every s-th pixel: numpy one-liners of the same rules."""
+    x = np.concatenate([rng.random(400) * 300 - 20, np.arange(0, 256) + 0.5, [-0.5, 255.5, 1e9, -1e9]]).astype(np.float32)
+    img = x[: (x.size // 6) * 6].reshape(-1, 6, 1)
+    assert np.array_equal(oracle.convert_8u(img), np.clip(np.rint(img.astype(np.float64)), 0, 255).astype(np.uint8))
+    a = (rng.random((9, 11, 3)) * 255).astype(np.float32)
+    b = (rng.standard_normal((9, 11, 3)) * 40).astype(np.float32)
+    for alpha, beta in ((1.0, -0.03), (1.0, 1.3), (0.5, 0.25)):
+        want = (a.astype(np.float64) * alpha + b.astype(np.float64) * beta).astype(np.float32)
+        assert np.array_equal(oracle.add_weighted(a, alpha, b, beta), want)
+    big = (rng.random((12, 20, 3)) * 255).astype(np.float32)
+    for s in (2, 4):
+        assert np.array_equal(oracle.resize_nearest(big, 12 // s, 20 // s), big[::s, ::s])
