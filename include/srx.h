@@ -125,7 +125,8 @@ SRX_API int srx_set_flow_builtin(srx_handle* h, int kind);
 SRX_API int srx_set_flow_callback(srx_handle* h, srx_flow_fn fn, void* user);
 SRX_API int srx_set_flow_callback2(srx_handle* h, srx_flow2_fn fn, void* user);
 /* parameters of the built-in flows.  TV-L1: tau, lambda, theta, epsilon (double); nscales, warps,
- * iterations (int).  Farneback (names of lib/include/optical_flow.hpp's class Farneback): pyrScale,
+ * iterations (int); iterationsPerLaunch (int: 0 = chosen by the size of the pyramid level, the default;
+ * 1, 4 or 8 = that kernel at every level - the flows and iteration counts are the same).  Farneback (names of lib/include/optical_flow.hpp's class Farneback): pyrScale,
  * polySigma (double); numLevels, winSize, numIters, polyN, flags (int; 0 = box window, 256 = Gaussian
  * window as OPTFLOW_FARNEBACK_GAUSSIAN; an initial flow, flag 4, is not built). */
 SRX_API int srx_flow_set_int(srx_handle* h, const char* name, int value);

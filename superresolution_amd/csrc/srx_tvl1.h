@@ -15,6 +15,9 @@ struct Tvl1Params
     int warps = 5;
     double epsilon = 0.01;
     int iterations = 300;
+    // inner iterations per kernel launch: 0 = by the size of the pyramid level (the default), 1, 4 or 8 = the
+    // kernel of that many iterations at every level (same flows and iteration counts; for tests and tuning)
+    int iterationsPerLaunch = 0;
 };
 
 int tvl1_set_int(Tvl1Params& p, const std::string& name, int value);

@@ -79,6 +79,16 @@ int launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t st)
 
 int tvl1_set_int(Tvl1Params& p, const std::string& n, int v)
 {
+    if (n == "iterationsPerLaunch")
+    {
+        if (v != 0 && v != 1 && v != 4 && v != 8)
+        {
+            set_error("flow parameter iterationsPerLaunch must be 0 (by level size), 1, 4 or 8");
+            return SRX_ERR_INVALID;
+        }
+        p.iterationsPerLaunch = v;
+        return SRX_OK;
+    }
     if (v < 1)
     {
         set_error("flow parameter " + n + " must be positive");
@@ -125,6 +135,8 @@ int tvl1_get_int(const Tvl1Params& p, const std::string& n, int* v)
         *v = p.warps;
     else if (n == "iterations")
         *v = p.iterations;
+    else if (n == "iterationsPerLaunch")
+        *v = p.iterationsPerLaunch;
     else
         return bad_name(n);
     return SRX_OK;
@@ -979,7 +991,9 @@ int Tvl1::calc_gray(const float* I0, const float* I1, int rows, int cols, const 
             float* pa[2] = {p11, m.p_alt.as<float>()};
             int& predicted = m.last_done[(size_t)s * p.warps + w];
             // 0: at most 200 000 pixels, 1: at most 1 000 000, 2: more
-            const int size_class = n > (size_t)1000000 ? 2 : (n > (size_t)200000 ? 1 : 0);
+            const int by_size = n > (size_t)1000000 ? 2 : (n > (size_t)200000 ? 1 : 0);
+            const int size_class = p.iterationsPerLaunch == 1 ? 2 : p.iterationsPerLaunch == 4 ? 1
+                                   : p.iterationsPerLaunch == 8 ? 0 : by_size;
             // Iterations per launch.  Small levels are bound by the time a launch takes whatever it does: 8 iterations
             // on tiles of 16 x 16.  Levels of a megapixel and more are bound by memory traffic, and the short row
             // segments of a tile with halo waste too much of every cache line: one iteration per launch on tiles

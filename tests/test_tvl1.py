@@ -86,6 +86,38 @@ def test_gpu_flow_matches_oracle_bit_exact(rows, cols, ch, dtype, kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("per_launch", [1, 4, 8])
+@pytest.mark.parametrize("rows,cols,kw", [
+    (64, 80, {}),                                             # width a multiple of 4: 16-byte single-iteration kernel
+    (33, 47, dict(nscales=3, warps=2, iterations=40)),        # odd width: the one-pixel-per-thread kernel
+    (150, 264, dict(nscales=3, warps=2, iterations=60)),      # several tiles of every kernel in both directions
+    (41, 132, dict(nscales=2, warps=2, iterations=30)),       # a tile column of 4 pixels behind a full one
+])
+def test_every_iteration_kernel_matches_the_oracle(rows, cols, kw, per_launch):
+    """The library picks the iteration kernel by the size of the pyramid level: 8 iterations per launch on small
+    levels, 4 on levels up to a megapixel, one above.  Images an oracle run can afford only ever reach the first, so
+    iterationsPerLaunch forces each kernel onto every level: flows and executed iteration counts must be the
+    oracle's with all of them."""
+    import torch
+    from superresolution_amd import api
+
+    a, b, _ = _pair(rows, cols, 1, 5 + rows)
+    ga, gb = tvl1.to_gray(a), tvl1.to_gray(b)
+    ref, n_ref = tvl1.calc_gray(ga, gb, tvl1.Tvl1Params(**kw))
+    sr = api.BTV_L1()
+    sr.setOpticalFlow(api.DualTVL1())
+    for k, v in kw.items():
+        sr.flowSet(k, v)
+    sr.flowSet("iterationsPerLaunch", per_launch)
+    flow, n = sr.calcFlowDevice(torch.from_numpy(ga).cuda(), torch.from_numpy(gb).cuda())
+    assert n == n_ref
+    assert np.array_equal(flow.cpu().numpy(), ref)
+    # a second call starts from the first one's predictions of the iteration counts (launch batches): same result
+    flow2, n2 = sr.calcFlowDevice(torch.from_numpy(ga).cuda(), torch.from_numpy(gb).cuda())
+    assert n2 == n_ref and torch.equal(flow, flow2)
+
+
+@pytest.mark.gpu
 def test_gpu_flow_device_entry_and_iteration_count():
     import torch
     from superresolution_amd import api
