@@ -77,6 +77,11 @@ CASES = [
     # and a strip boundary (more than 63 LR columns)
     (11, 12, 70, 3, 5, dict(iterations=3)),
     (13, 10, 16, 1, 0, dict(iterations=3)),
+    # scale 4 with more than 14 frames: the update kernel's packed sign sums are unpacked in mid-loop (its 10-bit
+    # fields hold 14 frames' worth); 33 frames are four passes of the forward kernel, 40 the largest window
+    (17, 10, 16, 3, 8, dict(iterations=3)),
+    (33, 8, 12, 1, 30, dict(iterations=2)),
+    (40, 8, 12, 3, 0, dict(iterations=2)),
 ]
 
 
