@@ -99,6 +99,27 @@ def test_process_matches_oracle_bit_exact(rng, K, rows, cols, ch, base, kw):
     assert np.array_equal(ref_out, out.cpu().numpy())
 
 
+def test_one_object_through_changing_sizes_windows_and_scales(rng):
+    """The solver's workspace only grows, and what it holds per frame (maps in several forms, sign planes, tile
+    headers) is laid out by the size of the call: a call must not see what an earlier call of another size, window
+    or scale left behind.  One object, calls of changing shape, each against the oracle."""
+    from superresolution_amd import api, ops
+
+    sr = api.BTV_L1()
+    calls = [(3, 12, 16, 3, dict(iterations=3, scale=2)), (5, 40, 72, 3, dict(iterations=3, scale=2)),
+             (9, 14, 70, 3, dict(iterations=2)), (2, 10, 12, 1, dict(iterations=3, scale=2)),
+             (4, 20, 24, 1, dict(iterations=2, scale=3, blur_kernel_size=3)), (5, 40, 72, 3, dict(iterations=2, scale=2)),
+             (3, 8, 8, 3, dict(iterations=2))]
+    for n, (K, rows, cols, ch, kw) in enumerate(calls):
+        p = oracle.BtvParams(**kw)
+        y, fl = make_case(rng, K, rows, cols, ch, p.scale, seed=900 + n)
+        ref_out, ref_full = oracle.btvl1_process(y, fl, K // 2, p, return_full=True)
+        set_params(sr, p)
+        out, full = ops.process_device(sr, [dev(f) for f in y], [dev(f) for f in fl], K // 2, return_full=True)
+        assert np.array_equal(ref_full, full.cpu().numpy()), f"call {n}"
+        assert np.array_equal(ref_out, out.cpu().numpy()), f"call {n}"
+
+
 @pytest.mark.parametrize("scale,rows,cols,ch,amp", [(4, 20, 24, 3, 4.0), (2, 20, 24, 3, 4.0), (2, 14, 132, 3, 2.0),
                                                     (2, 14, 132, 1, 9.0), (2, 16, 33, 3, 4.0)])
 def test_run_with_arbitrary_relative_motions(rng, scale, rows, cols, ch, amp):
