@@ -173,19 +173,24 @@ class TrueFlow:
         return f
 
 
-@pytest.mark.parametrize("n_frames,r,ch,mem", [(8, 2, 1, "host"), (7, 1, 3, "host"), (12, 4, 3, "host"),
-                                              (8, 2, 3, "device"), (5, 2, 1, "host"), (4, 0, 1, "host")])
-def test_streaming_matches_oracle(n_frames, r, ch, mem):
+@pytest.mark.parametrize("n_frames,r,ch,mem,shape", [
+    (8, 2, 1, "host", None), (7, 1, 3, "host", None), (12, 4, 3, "host", None), (8, 2, 3, "device", None),
+    (5, 2, 1, "host", None), (4, 0, 1, "host", None),
+    # scale 2 (8-bit frames reach its kernels as bytes), several tiles of the update kernel in both directions;
+    # scale 4 over two strips of the forward kernel
+    (7, 2, 3, "host", (40, 72, 2)), (6, 1, 1, "device", (24, 36, 2)), (6, 2, 3, "device", (12, 70, 4))])
+def test_streaming_matches_oracle(n_frames, r, ch, mem, shape):
     import torch
     from superresolution_amd import api, synth, _lib as L
 
-    rows, cols, s, T = 16, 20, 4, 6
+    rows, cols, s = shape or (16, 20, 4)
+    T = 6 if shape is None else 4
     lr, flows, _ = synth.make_sequence(n_frames, rows, cols, ch, s, seed=40 + n_frames)
     lr_np = [f.numpy() if ch == 3 else f.numpy()[:, :, 0] for f in lr]
     fl_np = [f.numpy() for f in flows]
 
     o = ostream.BTV_L1(TrueFlow(fl_np))
-    o.params = oracle.BtvParams(iterations=T)
+    o.params = oracle.BtvParams(iterations=T, scale=s)
     o.temporalAreaRadius = r
     o.setFrameSource(ostream.ListFrameSource(lr_np))
     ref = []
@@ -198,6 +203,7 @@ def test_streaming_matches_oracle(n_frames, r, ch, mem):
 
     sr = api.BTV_L1()
     sr.set("iterations", T)
+    sr.set("scale", s)
     sr.set("temporalAreaRadius", r)
     sr.set("traceEvents", 1)
     if mem == "device":
@@ -242,7 +248,7 @@ def test_source_and_flow_plugin_that_reuse_one_buffer(kind):
     lr_np = [f.numpy() for f in lr]
     fl_np = [f.numpy() for f in flows]
     o = ostream.BTV_L1(TrueFlow(fl_np))
-    o.params = oracle.BtvParams(iterations=T)
+    o.params = oracle.BtvParams(iterations=T, scale=s)
     o.temporalAreaRadius = r
     o.setFrameSource(ostream.ListFrameSource(lr_np))
     ref = []
