@@ -79,6 +79,10 @@ CASES = [
     (13, 10, 16, 1, 0, dict(iterations=3)),
     # scale 4 with more than 14 frames: the update kernel's packed sign sums are unpacked in mid-loop (its 10-bit
     # fields hold 14 frames' worth); 33 frames are four passes of the forward kernel, 40 the largest window
+    # the tiled forward kernel (other scales and blur sizes) over several tiles of 32 x 8 LR pixels per axis
+    (3, 20, 70, 3, 1, dict(iterations=3, scale=3)),
+    (3, 18, 40, 1, 0, dict(iterations=3, blur_kernel_size=7, blur_sigma=1.1)),
+    (2, 20, 36, 3, 1, dict(iterations=3, scale=2, blur_kernel_size=3)),
     (17, 10, 16, 3, 8, dict(iterations=3)),
     (33, 8, 12, 1, 30, dict(iterations=2)),
     (40, 8, 12, 3, 0, dict(iterations=2)),
