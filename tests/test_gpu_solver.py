@@ -252,7 +252,7 @@ def test_source_and_flow_plugin_that_reuse_one_buffer(kind):
     lr_np = [f.numpy() for f in lr]
     fl_np = [f.numpy() for f in flows]
     o = ostream.BTV_L1(TrueFlow(fl_np))
-    o.params = oracle.BtvParams(iterations=T, scale=s)
+    o.params = oracle.BtvParams(iterations=T)
     o.temporalAreaRadius = r
     o.setFrameSource(ostream.ListFrameSource(lr_np))
     ref = []
