@@ -70,6 +70,16 @@ def test_flow_parameters():
     assert i.value == 3
     with pytest.raises(L.SrxError):
         sr.flowSet("warps", 0)
+    # iterations per kernel launch: 0 (chosen by the size of the level) unless a kernel is asked for by name
+    L.check(lib.srx_flow_get_int(sr.handle, b"iterationsPerLaunch", C.byref(i)))
+    assert i.value == 0
+    for ok in (1, 4, 8, 0):
+        sr.flowSet("iterationsPerLaunch", ok)
+        L.check(lib.srx_flow_get_int(sr.handle, b"iterationsPerLaunch", C.byref(i)))
+        assert i.value == ok
+    for bad in (2, 3, 16, -1):
+        with pytest.raises(L.SrxError):
+            sr.flowSet("iterationsPerLaunch", bad)
 
 
 def test_ring_slot_and_window_match_oracle():
