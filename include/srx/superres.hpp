@@ -262,6 +262,9 @@ class BTV_L1_Base
     {
         check(srx_create_btvl1(device, &h_));
         opticalFlow = std::make_shared<Farneback>(); // opticalFlow = new Farneback, lib/src/btv_l1.cpp:287
+        // A new library object already runs Farneback with the defaults that fb_sent_ holds, so the default flow
+        // counts as bound: the first pushParams() sends nothing and leaves earlier setFlowParam() values alone.
+        bound_flow_ = opticalFlow;
     }
     virtual ~BTV_L1_Base() { srx_destroy(h_); }
     BTV_L1_Base(const BTV_L1_Base&) = delete;
@@ -288,6 +291,9 @@ class BTV_L1_Base
     double blurSigma = 0.0;
     Ptr<DenseOpticalFlow> opticalFlow;
 
+    // The C handle.  The public members above are the parameters' home: every process() / nextFrame() / calcFlow()
+    // sends members that differ from the library's values, so a solver parameter set through the handle alone
+    // lasts until the next such call; set the member (or BTV_L1::set) instead.
     srx_handle* handle() const { return h_; }
 
   protected:
@@ -354,6 +360,23 @@ class BTV_L1_Base
         else
             check(srx_set_flow_callback(h_, &BTV_L1_Base::flow_thunk, this));
         bound_flow_ = opticalFlow;
+    }
+
+    void mirrorFlowParam(const std::string& name, double v)
+    {
+        Farneback* fb = dynamic_cast<Farneback*>(opticalFlow.get());
+        if (!fb || opticalFlow != bound_flow_)
+            return;
+        for (Farneback* o : {fb, &fb_sent_})
+        {
+            if (name == "pyrScale") o->pyrScale = v;
+            else if (name == "numLevels") o->numLevels = (int)v;
+            else if (name == "winSize") o->winSize = (int)v;
+            else if (name == "numIters") o->numIters = (int)v;
+            else if (name == "polyN") o->polyN = (int)v;
+            else if (name == "polySigma") o->polySigma = v;
+            else if (name == "flags") o->flags = (int)v;
+        }
     }
 
     srx_handle* h_ = nullptr;
@@ -509,8 +532,18 @@ class BTV_L1 : public SuperResolution, private BTV_L1_Base
         bindFlow();
     }
     Ptr<DenseOpticalFlow> getOpticalFlow() const { return opticalFlow; }
-    void setFlowParam(const std::string& name, int v) { check(srx_flow_set_int(h_, name.c_str(), v)); }
-    void setFlowParam(const std::string& name, double v) { check(srx_flow_set_double(h_, name.c_str(), v)); }
+    // Parameters of the built-in flows by name.  Where the flow object is a Farneback, whose parameters are public
+    // members, the member takes the value too, so that a later edit of another member does not send the old one.
+    void setFlowParam(const std::string& name, int v)
+    {
+        check(srx_flow_set_int(h_, name.c_str(), v));
+        mirrorFlowParam(name, (double)v);
+    }
+    void setFlowParam(const std::string& name, double v)
+    {
+        check(srx_flow_set_double(h_, name.c_str(), v));
+        mirrorFlowParam(name, v);
+    }
 
     // ---- SuperResolution (lib/src/super_resolution.cpp:131-152)
     void setFrameSource(const Ptr<IFrameSource>& frameSource) override

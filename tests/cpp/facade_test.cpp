@@ -261,6 +261,31 @@ int main()
         }
         REQUIRE(threw);
     }
+    // flow parameters set by name before the first frame stay set (the default Farneback counts as bound, so the
+    // first nextFrame() does not send the object's defaults over them), and editing another member of the flow
+    // object afterwards sends that member without taking the named value back
+    {
+        BTV_L1 named(-1);
+        named.setFlowParam("numLevels", 3);
+        named.setFlowParam("polySigma", 1.5);
+        named.set("temporalAreaRadius", 1);
+        named.setFrameSource(std::make_shared<Source16>(4));
+        REQUIRE(!named.nextFrame().empty());
+        int levels = 0, win = 0;
+        double sigma = 0;
+        REQUIRE(srx_flow_get_int(named.handle(), "numLevels", &levels) == SRX_OK && levels == 3);
+        REQUIRE(srx_flow_get_double(named.handle(), "polySigma", &sigma) == SRX_OK && sigma == 1.5);
+        Farneback* fb = dynamic_cast<Farneback*>(named.getOpticalFlow().get());
+        REQUIRE(fb && fb->numLevels == 3 && fb->polySigma == 1.5);
+        fb->winSize = 9;
+        REQUIRE(!named.nextFrame().empty());
+        REQUIRE(srx_flow_get_int(named.handle(), "winSize", &win) == SRX_OK && win == 9);
+        REQUIRE(srx_flow_get_int(named.handle(), "numLevels", &levels) == SRX_OK && levels == 3);
+        named.setFlowParam("numIters", 4);
+        REQUIRE(!named.nextFrame().empty());
+        int iters = 0;
+        REQUIRE(srx_flow_get_int(named.handle(), "numIters", &iters) == SRX_OK && iters == 4);
+    }
     std::puts("facade ok");
     return 0;
 }
