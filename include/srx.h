@@ -158,7 +158,9 @@ SRX_API int srx_set_output_range(srx_handle* h, int first, int last);
  * computed by the flow plug-in) and :328-355 (n-1 consecutive forward
  * motions).  frames: n images of equal size/type (8U or 32F, 1 or 3
  * channels).  out: caller buffer (host or device) of
- * (rows*scale-2B) x (cols*scale-2B), same depth as the frames. */
+ * (rows*scale-2B) x (cols*scale-2B), same depth as the frames.  A dry-run
+ * handle (device -1) checks every argument and calls the flow plug-in as
+ * often as a GPU handle would, writes nothing to out and returns SRX_OK. */
 SRX_API int srx_process(srx_handle* h, const srx_image* frames, int n, const srx_image* motions, int base_idx,
                         srx_image* out);
 
@@ -292,7 +294,10 @@ SRX_API int srx_quality_mssim(const srx_image* a, const srx_image* b, double* pe
  * GPU's memory from load to exit; the call makes no hipMalloc / hipFree and uses no
  * allocating library routine (two kernel launches, an 8-byte copy to the host, a
  * stream synchronise).  All calls on one GPU share that array: calls that overlap
- * in time on one GPU (other streams, other threads) race; order them. */
+ * in time on one GPU (other streams, other threads) race; order them.  Both
+ * images must be plain device memory of the GPU that is current in the calling
+ * thread (the stream is one of that GPU's): anything else is refused with
+ * SRX_ERR_INVALID before a kernel is launched. */
 SRX_API int srx_quality_psnr_noalloc(const srx_image* a, const srx_image* b, double* psnr, void* stream);
 
 /* BTV_L1_Base::run, lib/src/btv_l1.cpp:357-457, on device-resident inputs

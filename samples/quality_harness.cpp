@@ -87,6 +87,26 @@ class GoldSource : public IFrameSource
     int rows_, cols_, ch_, frames_, t_ = 0;
 };
 
+// AllignedFrameSource of samples/quality_test/main.cpp:43-75: a frame whose size is not a multiple of the scale is
+// cut to the largest such size, anchored at the top-left corner (a view of the same memory, as Mat::operator()(Rect)).
+class AlignedSource : public IFrameSource
+{
+  public:
+    AlignedSource(Ptr<IFrameSource> base, int scale) : base_(base), scale_(scale) {}
+    void reset() override { base_->reset(); }
+    Mat nextFrame() override
+    {
+        Mat frame = base_->nextFrame();
+        if (!frame.empty() && (frame.rows() % scale_ != 0 || frame.cols() % scale_ != 0))
+            frame = frame.roi(0, 0, (frame.cols() / scale_) * scale_, (frame.rows() / scale_) * scale_);
+        return frame;
+    }
+
+  private:
+    Ptr<IFrameSource> base_;
+    int scale_;
+};
+
 // blur + decimate (+ noise) of another source's frames
 class DegradedSource : public IFrameSource
 {
@@ -313,6 +333,36 @@ int selftest()
             if ((int)std::floor(s + 0.5) != d.ptr<uint8_t>(y)[x])
                 ++bad;
         }
+    // AlignedSource: a 13 x 18 clip at scale 4 becomes 12 x 16, the same pixels as the top-left corner of the source,
+    // the degraded frame is 3 x 4, and a size that already fits passes through untouched
+    {
+        AlignedSource al(Ptr<IFrameSource>(new GoldSource(13, 18, 3, 2)), 4);
+        GoldSource plain(13, 18, 3, 2);
+        const Mat a = al.nextFrame(), g = plain.nextFrame();
+        if (a.rows() != 12 || a.cols() != 16 || a.channels() != 3)
+            ++bad;
+        else
+            for (int y = 0; y < 12; ++y)
+                if (std::memcmp(a.ptr<uint8_t>(y), g.ptr<uint8_t>(y), 16 * 3) != 0)
+                    ++bad;
+        DegradedSource dal(Ptr<IFrameSource>(new AlignedSource(Ptr<IFrameSource>(new GoldSource(13, 18, 3, 2)), 4)), 4, false);
+        DegradedSource dcut(Ptr<IFrameSource>(new GoldSource(12, 16, 3, 2)), 4, false);
+        const Mat d1 = dal.nextFrame();
+        if (d1.rows() != 3 || d1.cols() != 4)
+            ++bad;
+        // the cut comes first (main.cpp:269-271), so the blur reflects at the cut edge: the degraded frame equals that
+        // of a clip generated at 12 x 16 (GoldSource's pixel values do not depend on the clip's size)
+        const Mat d2 = dcut.nextFrame();
+        for (int y = 0; y < 3 && d1.rows() == 3 && d1.cols() == 4; ++y)
+            if (std::memcmp(d1.ptr<uint8_t>(y), d2.ptr<uint8_t>(y), 4 * 3) != 0)
+                ++bad;
+        AlignedSource fits(Ptr<IFrameSource>(new GoldSource(12, 16, 1, 1)), 4);
+        const Mat f = fits.nextFrame();
+        if (f.rows() != 12 || f.cols() != 16 || f.step() != 16)
+            ++bad;
+        if (!fits.nextFrame().empty())
+            ++bad;
+    }
     std::printf("selftest: %s (%d mismatches)\n", bad ? "FAILED" : "ok", bad);
     return bad ? 1 : 0;
 }
@@ -323,7 +373,8 @@ int main(int argc, char** argv)
         return selftest();
     const int scale = arg_int(argc, argv, "--scale", 4), iterations = arg_int(argc, argv, "--iterations", 180);
     const int temporal = arg_int(argc, argv, "--temporal", 4);
-    const int rows = arg_int(argc, argv, "--rows", 240) / scale * scale, cols = arg_int(argc, argv, "--cols", 320) / scale * scale;
+    // the clip may have any size: every source is wrapped in an AlignedSource, as at main.cpp:269-271
+    const int rows = arg_int(argc, argv, "--rows", 240), cols = arg_int(argc, argv, "--cols", 320);
     const int ch = arg_int(argc, argv, "--channels", 1), frames = arg_int(argc, argv, "--frames", 12);
     const bool noise = arg_flag(argc, argv, "--noise");
     // --opt-flow farneback | tvl1; farneback is the default of samples/quality_test/main.cpp:209
@@ -346,9 +397,12 @@ int main(int argc, char** argv)
         superRes->set("temporalAreaRadius", temporal);
         superRes->setOpticalFlow(optFlow == "tvl1" ? createOptFlow_DualTVL1() : createOptFlow_Farneback());
 
-        Ptr<IFrameSource> gold(new GoldSource(rows, cols, ch, frames));
-        Ptr<IFrameSource> lowRes(new DegradedSource(Ptr<IFrameSource>(new GoldSource(rows, cols, ch, frames)), scale, noise));
-        Ptr<IFrameSource> lowRes2(new DegradedSource(Ptr<IFrameSource>(new GoldSource(rows, cols, ch, frames)), scale, noise));
+        auto aligned = [&]() {
+            return Ptr<IFrameSource>(new AlignedSource(Ptr<IFrameSource>(new GoldSource(rows, cols, ch, frames)), scale));
+        };
+        Ptr<IFrameSource> gold = aligned();
+        Ptr<IFrameSource> lowRes(new DegradedSource(aligned(), scale, noise));
+        Ptr<IFrameSource> lowRes2(new DegradedSource(aligned(), scale, noise));
         // "skip first frame, it is usually corrupted" (main.cpp:273-287): all three sources drop their first
         // frame before the super-resolution object sees its source, so the table starts at the clip's second frame
         {
@@ -360,8 +414,8 @@ int main(int argc, char** argv)
         }
         superRes->setFrameSource(lowRes);
 
-        std::printf("Input             : synthetic %dx%d, %d channel(s), %d frames%s\n", cols, rows, ch, frames,
-                    noise ? ", noise" : "");
+        std::printf("Input             : synthetic %dx%d (used: %dx%d), %d channel(s), %d frames%s\n", cols, rows,
+                    cols / scale * scale, rows / scale * scale, ch, frames, noise ? ", noise" : "");
         std::printf("Scale factor      : %d\nIterations        : %d\nFrames to process : %d\nOptical Flow      : %s\n"
                     "Mode              : GPU\n\n",
                     scale, iterations, 2 * temporal + 1, optFlow.c_str());

@@ -315,6 +315,14 @@ class BTV_L1:
         s, B = self.getInt("scale"), self.getInt("btvKernelSize")
         f0 = frames[0]
         shape = (f0.rows * s - 2 * B, f0.cols * s - 2 * B, f0.channels)
+        if self._device < 0:
+            # dry-run handle: arguments are checked and the flow plug-in is called, nothing is computed; the
+            # result is the output's shape, as nextFrame() gives sizes only on such a handle
+            L.check(self._lib.srx_process(self._h, frames, n, motions, baseIdx,
+                                          C.byref(_describe(np.empty(shape, np.uint8 if f0.depth == L.SRX_8U else
+                                                                     np.uint16 if f0.depth == L.SRX_16U else np.float32),
+                                                            keep))))
+            return shape
         if out is None:
             if f0.mem == L.SRX_MEM_DEVICE:
                 import torch

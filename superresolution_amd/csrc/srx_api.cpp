@@ -867,9 +867,35 @@ SRX_API int srx_set_output_range(srx_handle* h, int first, int last)
     return SRX_OK;
 }
 
+// Caller memory handed over during a call (source frames, flow plug-in results) may be reused once the call
+// returns: whatever reads of it are still queued on the handle's stream are waited for on every way out.
+static int release_caller_memory(srx_handle* h, int rc)
+{
+    if (h->dry)
+        return rc;
+    if (rc != SRX_OK)
+    {
+        // an error return may leave copies of caller memory queued that no event marks
+        if (hipStreamSynchronize(h->stream) != hipSuccess)
+            (void)hipGetLastError();
+        h->caller_read_pending = false;
+        return rc;
+    }
+    return h->wait_caller_reads();
+}
+
+static int next_frame_impl(srx_handle* h, srx_image* out);
+static int process_batch_impl(srx_handle* h, const srx_image* frames, int n, const srx_image* motions, int base_idx,
+                              srx_image* out);
+
 SRX_API int srx_next_frame(srx_handle* h, srx_image* out)
 {
     SRX_NEED(h);
+    return release_caller_memory(h, next_frame_impl(h, out));
+}
+
+static int next_frame_impl(srx_handle* h, srx_image* out)
+{
     if (!out)
     {
         set_error("out is NULL");
@@ -921,6 +947,12 @@ SRX_API int srx_process(srx_handle* h, const srx_image* frames, int n, const srx
                         srx_image* out)
 {
     SRX_NEED(h);
+    return release_caller_memory(h, process_batch_impl(h, frames, n, motions, base_idx, out));
+}
+
+static int process_batch_impl(srx_handle* h, const srx_image* frames, int n, const srx_image* motions, int base_idx,
+                              srx_image* out)
+{
     // a dry-run handle checks the arguments and calls the flow plug-in as often as a real one, and computes nothing
     const bool dry = h->dry;
     if (!frames || !out || n < 1 || n > kMaxWindow || base_idx < 0 || base_idx >= n)

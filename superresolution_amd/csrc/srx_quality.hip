@@ -81,11 +81,38 @@ constexpr int kMaxScratchDevices = 64;
 std::mutex g_scratch_mutex;
 unsigned long long* g_scratch_ptr[kMaxScratchDevices] = {};
 
-// Address of `scratch` on the current device, looked up once per device.
-int scratch_of_current_device(unsigned long long** out)
+// The GPU that owns a device pointer, or an error for anything that is not plain device memory.
+int device_of_pointer(const void* p, const char* which, int* dev)
 {
-    int dev = -1;
+    hipPointerAttribute_t attr{};
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess || attr.type != hipMemoryTypeDevice)
+    {
+        (void)hipGetLastError();
+        set_error(std::string("psnr (no allocation): image ") + which + " is not in device memory");
+        return SRX_ERR_INVALID;
+    }
+    *dev = attr.device;
+    return SRX_OK;
+}
+
+// Address of `scratch` on the current device, looked up once per device.  Both images must live on that device:
+// every GPU has its own copy of the array at its own address, and the caller's stream belongs to the current
+// device, so an image of another GPU is refused rather than handed a foreign array.
+int scratch_of_current_device(const srx_image& a, const srx_image& b, unsigned long long** out)
+{
+    int dev = -1, dev_a = -1, dev_b = -1;
     SRX_HIP(hipGetDevice(&dev));
+    if (int rc = device_of_pointer(a.data, "a", &dev_a))
+        return rc;
+    if (int rc = device_of_pointer(b.data, "b", &dev_b))
+        return rc;
+    if (dev_a != dev || dev_b != dev)
+    {
+        set_error("psnr (no allocation): the images live on GPU " + std::to_string(dev_a) + " and GPU " +
+                  std::to_string(dev_b) + " but the current device is GPU " + std::to_string(dev) +
+                  " (make the images' device current and pass one of its streams)");
+        return SRX_ERR_INVALID;
+    }
     if (dev < 0 || dev >= kMaxScratchDevices)
     {
         set_error("psnr (no allocation): device index out of range");
@@ -330,7 +357,7 @@ int quality_psnr_noalloc(const srx_image& a, const srx_image& b, double* psnr, h
         return SRX_ERR_INVALID;
     }
     unsigned long long* part = nullptr;
-    if (int rc = scratch_of_current_device(&part))
+    if (int rc = scratch_of_current_device(a, b, &part))
         return rc;
     const size_t rb = (size_t)rowbytes;
     hipLaunchKernelGGL(k_sqdiff_8u, dim3((unsigned)blocks), dim3(256), 0, st, (const uint8_t*)a.data,

@@ -27,36 +27,70 @@ def span_plan(total_frames: int, radius: int, world: int, rank: int) -> Tuple[in
     return tuple(x.value for x in v)
 
 
+def _check_span_lengths(n_own: int, like: torch.Tensor, radius: int, rank: int, world: int, group) -> None:
+    """Every rank learns every span length (one int per rank, a control message outside the data path) and applies
+    the same rule to all of them, so that either all ranks go on to the exchange or all of them raise: a rank that
+    refused on its own would leave its neighbours waiting for messages that never come."""
+    mine = torch.tensor([n_own], dtype=torch.int64, device=like.device)
+    lengths = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(lengths, mine, group=group)
+    for g, n in enumerate(int(t.item()) for t in lengths):
+        edge = g == 0 or g == world - 1
+        if n < radius + (1 if edge else 0):
+            raise ValueError(f"rank {g} holds {n} frames: every span must hold at least `radius` = {radius} frames, "
+                             f"the first and the last `radius` + 1 (span_plan refuses such partitions)")
+
+
+class HaloExchange:
+    """The halo swap of one rank in flight: post() starts the sends and receives, wait() returns the halos.
+    Work that does not need the neighbours' frames (synthesis, uploads, the first windows of an inner span's
+    warm-up) can run between the two."""
+
+    def __init__(self, own: Sequence[torch.Tensor], radius: int, rank: Optional[int] = None,
+                 world: Optional[int] = None, group=None, check: bool = True):
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.left: List[torch.Tensor] = []
+        self.right: List[torch.Tensor] = []
+        self._reqs = []
+        self._keep = []
+        rank, world = self.rank, self.world
+        if radius == 0 or world == 1:
+            return
+        if check:
+            _check_span_lengths(len(own), own[0], radius, rank, world, group)
+        self.left = [torch.empty_like(own[0]) for _ in range(radius)] if rank > 0 else []
+        self.right = [torch.empty_like(own[0]) for _ in range(radius)] if rank < world - 1 else []
+        ops = []
+        for i in range(radius):
+            if rank > 0:
+                ops.append(dist.P2POp(dist.isend, own[i].contiguous(), rank - 1, group))
+                ops.append(dist.P2POp(dist.irecv, self.left[i], rank - 1, group))
+            if rank < world - 1:
+                ops.append(dist.P2POp(dist.isend, own[len(own) - radius + i].contiguous(), rank + 1, group))
+                ops.append(dist.P2POp(dist.irecv, self.right[i], rank + 1, group))
+        self._keep = [op.tensor for op in ops]      # the send buffers stay alive until wait()
+        self._reqs = dist.batch_isend_irecv(ops)
+
+    def wait(self) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+        for req in self._reqs:
+            req.wait()
+        self._reqs, self._keep = [], []
+        return self.left, self.right
+
+
 def exchange_halo(own: Sequence[torch.Tensor], radius: int, rank: Optional[int] = None, world: Optional[int] = None,
                   group=None) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
     """Swap span-boundary frames with the neighbouring ranks.
 
     `own` holds this rank's frames in stream order (all ranks: same shape and dtype; at least `radius` frames,
     and `radius` + 1 on the first and the last rank, which have one halo only and whose streams otherwise could
-    not warm up - `span_plan` refuses such partitions).
+    not warm up - `span_plan` refuses such partitions, and so does this function, on every rank alike).
     Returns (left_halo, right_halo): the last `radius` frames of rank-1 and the first `radius` frames of rank+1
-    (empty lists at the ends of the stream).  Point-to-point only; no collective touches the data path.
+    (empty lists at the ends of the stream).  The frames travel point to point; the only collective is the
+    gather of one integer per rank (the span lengths) that makes the refusal uniform.
     """
-    rank = dist.get_rank(group) if rank is None else rank
-    world = dist.get_world_size(group) if world is None else world
-    if radius == 0 or world == 1:
-        return [], []
-    edge = rank == 0 or rank == world - 1
-    if len(own) < radius + (1 if edge else 0):
-        raise ValueError("every span must hold at least `radius` frames, the first and the last `radius` + 1")
-    left = [torch.empty_like(own[0]) for _ in range(radius)] if rank > 0 else []
-    right = [torch.empty_like(own[0]) for _ in range(radius)] if rank < world - 1 else []
-    ops = []
-    for i in range(radius):
-        if rank > 0:
-            ops.append(dist.P2POp(dist.isend, own[i].contiguous(), rank - 1, group))
-            ops.append(dist.P2POp(dist.irecv, left[i], rank - 1, group))
-        if rank < world - 1:
-            ops.append(dist.P2POp(dist.isend, own[len(own) - radius + i].contiguous(), rank + 1, group))
-            ops.append(dist.P2POp(dist.irecv, right[i], rank + 1, group))
-    for req in dist.batch_isend_irecv(ops):
-        req.wait()
-    return left, right
+    return HaloExchange(own, radius, rank, world, group).wait()
 
 
 def pair_shard(total_pairs: int, world: int, rank: int) -> Tuple[int, int]:

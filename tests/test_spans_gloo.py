@@ -141,3 +141,54 @@ def test_pair_shards_cover_every_pair_once():
             assert max(b - a for a, b in cuts) - min(b - a for a, b in cuts) <= 1
     with pytest.raises(ValueError):
         spans.pair_shard(4, 2, 2)
+
+
+def _refusal_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from superresolution_amd import spans
+
+        # the last rank holds `radius` frames only: too few for an edge span.  The middle rank's own span is fine,
+        # yet it must refuse as well instead of waiting for a neighbour that never posts its messages.
+        n_own = RADIUS if rank == world - 1 else RADIUS + 2
+        own = [torch.from_numpy(_frame(10 * rank + t)) for t in range(n_own)]
+        try:
+            spans.exchange_halo(own, RADIUS)
+            refused = ""
+        except ValueError as e:
+            refused = str(e)
+        # and with spans every rank accepts, the exchange posted early and waited for later gives the same halos
+        own = [torch.from_numpy(_frame(10 * rank + t)) for t in range(RADIUS + 1)]
+        ex = spans.HaloExchange(own, RADIUS)
+        busy = sum(int(f.sum()) for f in own)       # something to do while the frames travel
+        left, right = ex.wait()
+        ok = busy > 0 and len(left) == (RADIUS if rank > 0 else 0) and len(right) == (RADIUS if rank < world - 1 else 0)
+        for i, f in enumerate(left):
+            ok &= bool(np.array_equal(f.numpy(), _frame(10 * (rank - 1) + 1 + i)))
+        for i, f in enumerate(right):
+            ok &= bool(np.array_equal(f.numpy(), _frame(10 * (rank + 1) + i)))
+        q.put((rank, refused, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_span_that_is_too_short_is_refused_on_every_rank_alike():
+    world = 3
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_refusal_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, refused, ok in res:
+        assert "rank 2 holds 2 frames" in refused, (rank, refused)
+        assert ok, f"rank {rank}: halos of the in-flight exchange differ"

@@ -63,3 +63,39 @@ def test_no_allocation_psnr_refuses_what_it_cannot_hold():
     h = np.zeros((8, 8), np.uint8)
     with pytest.raises(L.SrxError, match="device memory"):
         quality.PSNR(h, h, allocate=False)
+
+
+def test_no_allocation_psnr_allocates_nothing_and_checks_who_owns_the_images():
+    import ctypes as C
+
+    import torch
+    from superresolution_amd import quality, _lib as L
+
+    a, b = _pair(torch, 480, 640, 3, 5)
+    want = quality.PSNR(a, b)
+    quality.PSNR(a, b, allocate=False)        # the first call on a device looks the array's address up
+    torch.cuda.synchronize()
+    free_before, _ = torch.cuda.mem_get_info()
+    for _ in range(3):
+        assert _bits(quality.PSNR(a, b, allocate=False)) == _bits(want)
+    torch.cuda.synchronize()
+    free_after, _ = torch.cuda.mem_get_info()
+    assert free_after == free_before          # hipMemGetInfo: not a byte of device memory taken
+    # a host pointer labelled as device memory is refused before any kernel sees it
+    host = torch.zeros((16, 16, 1), dtype=torch.uint8).pin_memory()
+    keep: list = []
+    hh = quality._header(host, keep)
+    hh.mem = L.SRX_MEM_DEVICE
+    out = C.c_double()
+    rc = L.lib().srx_quality_psnr_noalloc(C.byref(hh), C.byref(hh), C.byref(out), None)
+    assert rc == L.SRX_ERR_INVALID
+    with pytest.raises(L.SrxError, match="not in device memory"):
+        L.check(rc)
+    # images of another GPU than the current one are refused (needs two visible GPUs)
+    if torch.cuda.device_count() > 1:
+        with torch.cuda.device(1):
+            a1, b1 = a.to("cuda:1"), b.to("cuda:1")
+            assert _bits(quality.PSNR(a1, b1, allocate=False)) == _bits(want)   # device 1 current: its own array
+        with pytest.raises(L.SrxError, match="current device"):
+            ha, hb = quality._header(a1, keep), quality._header(b1, keep)
+            L.check(L.lib().srx_quality_psnr_noalloc(C.byref(ha), C.byref(hb), C.byref(out), None))
