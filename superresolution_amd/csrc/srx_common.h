@@ -114,15 +114,20 @@ int launch_sign_unpair(const uint32_t* pairs, uint32_t* plain, int lr_rows, int 
 // (generic_plane_stride 0) or planar with that plane stride.
 // y_bytes (optional): the same LR frames as 8-bit originals (rows x cols x ch bytes each); the specialised
 // scale-4 and scale-2 kernels then read those instead of the float copies (same values, a quarter of the bytes).
+// still_frame (optional hint, -1 = none): a frame whose motion is zero (the base frame of a window).  It only
+// decides which wave of the specialised scale-4 kernel works on which frame; results do not depend on it.
 int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const PtrList& raw_bwd,
                         const PtrList* dec_bwd, const PtrList& y, const MutPtrList& signs, int K, int scale,
                         const GaussK& g, size_t generic_plane_stride, hipStream_t st,
-                        const PtrList* y_bytes = nullptr);
+                        const PtrList* y_bytes = nullptr, int still_frame = -1);
 // With dec_fwd (and an eligible parameter set) the specialised kernel runs; it
 // wants X and X_out planar and the signs as pair planes (sign_pair_bytes).
+// identity_frame (-1 = none): a frame whose forward map is known to be the identity (zero motion: the base frame
+// of a window built by calcRelativeMotions).  The specialised scale-4 kernel then derives that frame's entries
+// from the pixel's own place instead of reading them; the caller vouches for the map, the values are the same.
 int launch_backproject_update(const float* X, float* X_out, int hr_rows, int hr_cols, int ch, const PtrList& raw_fwd,
                               const PtrList* dec_fwd, const PtrList& signs, int K, int scale, const GaussK& g,
-                              const BtvW& w, double tau, double lambda, hipStream_t st);
+                              const BtvW& w, double tau, double lambda, hipStream_t st, int identity_frame = -1);
 int launch_crop_convert(const float* X, int rows, int cols, int ch, int border, void* dst, int depth,
                         size_t plane_stride, hipStream_t st);
 int launch_convert_8u_to_32f(const uint8_t* src, size_t count, float* dst, hipStream_t st);

@@ -162,6 +162,7 @@ class Solver
     DeviceBuffer x_[2];
     const uint8_t* y8_[kMaxWindow] = {};
     int y8_count_ = 0;
+    int still_frame_ = -1; // window frame whose relative motion process() has just set to zero (else -1)
     int cur_ = 0;
     size_t ps_ = 0; // plane stride of x_ (0: interleaved)
     CubicTablesDev tables_;

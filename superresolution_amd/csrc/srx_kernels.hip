@@ -1019,7 +1019,7 @@ inline size_t forward_lds_bytes(int ch)
 template <int CH, bool Y8>
 __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sign_lds(
     const float* __restrict__ X, int H, int W, size_t ps, PtrList raw_bwd, PtrList grp_bwd, PtrList ys, MutPtrList signs,
-    int K, GaussK g, int strips_x, int rows_per_tile, unsigned n_tiles)
+    int K, GaussK g, int strips_x, int rows_per_tile, unsigned n_tiles, int frame_shift)
 {
     extern __shared__ __align__(16) char ring[];
     constexpr int kSlotBytes = CH * kFwdRowBytes;
@@ -1041,7 +1041,10 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
     const bool active = kw < K;
     // a spare wave shadows frame 0 (it still stages and meets the barriers); wave-uniform, so that
     // everything derived from the frame's pointers stays in scalar registers
-    const int k = __builtin_amdgcn_readfirstlane(active ? kw : 0);
+    // Wave kw works on frame (kw + frame_shift) mod K: the launcher picks the shift so that a frame with zero
+    // motion (the cheapest one: no map entries, no address arithmetic) goes to the last wave, which in a block
+    // of 4n+1 waves sits on the SIMD that carries a wave more than the others.
+    const int k = __builtin_amdgcn_readfirstlane(active ? (kw + frame_shift >= K ? kw + frame_shift - K : kw + frame_shift) : 0);
     const int x0 = strip * kFwdStrip, y0 = rg * rows_per_tile;
     const int y1 = min(y0 + rows_per_tile, h);
 
@@ -1944,7 +1947,8 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
 template <int CH, int FOOT>
 __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B3_WAVES) void k_backproject_update_s4(
     const float* __restrict__ X, float* __restrict__ X_out, int H, int W, size_t ps, PtrList dec_fwd,
-    PtrList signs, int K, FastW fw, BtvW bw, double tau, double lambda, int tiles_x, unsigned n_tiles)
+    PtrList signs, int K, FastW fw, BtvW bw, double tau, double lambda, int tiles_x, unsigned n_tiles,
+    const void* __restrict__ still_signs)
 {
     constexpr int kThreads = SRX_B_THREADS, TYN = kThreads / 16, PXT = 4;
     constexpr int TW = 16 * PXT;        // 64 px
@@ -2251,6 +2255,49 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B3_WAV
             accv[p] = 0;
         int pending = 0;
         uint32_t hd_now = 0; // scale 2: header of the current frame's tile (wave-uniform)
+        // scale 4: the four pixels' 2x2 blocks of sign cells of one frame times the entries' weights
+        auto gather4 = [&](const char* sg, const uint32_t (&ev)[PXT]) {
+            uint4_a8 qs[PXT];
+#pragma unroll
+            for (int p = 0; p < PXT; ++p)
+                qs[p] = *(const uint4_a8*)(sg + (ev[p] & kFwdCellMask));
+            __builtin_amdgcn_sched_barrier(0); // all four gathers are in flight before the first is consumed
+#pragma unroll
+            for (int p = 0; p < PXT; ++p)
+            {
+                const uint32_t e = ev[p];
+                const uint4_a8 q = qs[p];
+                const char* le = lutb + ((e >> (kFwdLutShift - 4)) & 0x1F0u);
+                const uint4 wq = *(const uint4*)le;
+                uint32_t v = accv[p];
+                v = mad_u24(q.x, wq.x, v);
+                v = mad_u24(q.y, wq.y, v);
+                v = mad_u24(q.z, wq.z, v);
+                v = mad_u24(q.w, wq.w, v);
+                accv[p] = v;
+                bias[p] += *(const uint32_t*)(le + kFwdLutSize * 16);
+            }
+        };
+        // A frame without motion (scale 4): its forward map is the identity, so its entries follow from the
+        // pixels' own place (decode_fwd of (j + p, i)) and are not read.  Integer sums: the order of the frames
+        // is free, this one goes first, while the first frame's entries are still on their way.
+        if (FOOT == 2 && still_signs)
+        {
+            const int py = i & 3;
+            const uint32_t cell = (uint32_t)(((i >> 2) + (py == 3)) * (W >> 2) + (j >> 2)) * 8u;
+            const uint32_t ly = (uint32_t)(5 * (i == H - 2 ? 4 : py)) << kFwdLutShift;
+            const bool last_row = i >= H - 1;
+            uint32_t ev[PXT];
+#pragma unroll
+            for (int p = 0; p < PXT; ++p)
+            {
+                const uint32_t lx = (uint32_t)((p == 2 && j == W - 4) ? 4 : p) << kFwdLutShift;
+                const bool none = last_row || (p == 3 && j == W - 4); // decode_fwd: targets in the last row / column
+                ev[p] = none ? kFwdLutZero << kFwdLutShift : (cell + (p == 3 ? 8u : 0u)) | (lx + ly);
+            }
+            gather4((const char*)still_signs, ev);
+            pending = 1;
+        }
         // one window frame: gathers through the entries in `now` while the next frame's entries arrive in `next`
         auto frame = [&](int k, const uint4& now, uint4& next) {
             if (k + 1 < K)
@@ -2266,28 +2313,7 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B3_WAV
             const char* sg = (const char*)signs.p[k];
             const uint32_t ev[PXT] = {now.x, now.y, now.z, now.w};
             if (FOOT == 2)
-            {
-                uint4_a8 qs[PXT];
-#pragma unroll
-                for (int p = 0; p < PXT; ++p)
-                    qs[p] = *(const uint4_a8*)(sg + (ev[p] & kFwdCellMask));
-                __builtin_amdgcn_sched_barrier(0); // all four gathers are in flight before the first is consumed
-#pragma unroll
-                for (int p = 0; p < PXT; ++p)
-                {
-                    const uint32_t e = ev[p];
-                    const uint4_a8 q = qs[p];
-                    const char* le = lutb + ((e >> (kFwdLutShift - 4)) & 0x1F0u);
-                    const uint4 wq = *(const uint4*)le;
-                    uint32_t v = accv[p];
-                    v = mad_u24(q.x, wq.x, v);
-                    v = mad_u24(q.y, wq.y, v);
-                    v = mad_u24(q.z, wq.z, v);
-                    v = mad_u24(q.w, wq.w, v);
-                    accv[p] = v;
-                    bias[p] += *(const uint32_t*)(le + kFwdLutSize * 16);
-                }
-            }
+                gather4(sg, ev);
             else if (hd_now & kSgFit)
             {
                 // the tile's patch of this frame is in LDS: nine cells per pixel from there
@@ -2413,6 +2439,14 @@ __global__ __launch_bounds__(SRX_B_THREADS, FOOT == 2 ? SRX_B_WAVES : SRX_B3_WAV
         }
         if (k < K)
             step(k, cur, alt, 0);
+        if (pending) // (only the frame without motion was there)
+        {
+#pragma unroll
+            for (int p = 0; p < PXT; ++p)
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    acc[p][c] += (int)((accv[p] >> (10 * c)) & 1023u);
+        }
     }
     SRX_STAMP(5);
     // ---- update
@@ -2688,7 +2722,7 @@ bool forward_fast_eligible(int hr_rows, int hr_cols, int ch, int scale, const Ga
 
 int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const PtrList& raw_bwd,
                         const PtrList* dec_bwd, const PtrList& y, const MutPtrList& signs, int K, int scale,
-                        const GaussK& g, size_t generic_plane_stride, hipStream_t st, const PtrList* y_bytes)
+                        const GaussK& g, size_t generic_plane_stride, hipStream_t st, const PtrList* y_bytes, int still_frame)
 {
     if (ch != 1 && ch != 3)
     {
@@ -2735,21 +2769,23 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
         const unsigned n_tiles = (unsigned)strips_x * row_groups;
         const dim3 gr(xcd_grid(n_tiles), passes), b(64 * waves);
         const size_t lds = forward_lds_bytes(ch);
+        // the still frame goes to the last wave of the (single) pass
+        const int shift = passes == 1 && still_frame >= 0 && still_frame < K ? (still_frame + 1) % K : 0;
         if (y_bytes)
         {
             if (ch == 1)
                 hipLaunchKernelGGL((k_forward_sign_lds<1, true>), gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd,
-                                   *y_bytes, signs, K, g, strips_x, rows_per_tile, n_tiles);
+                                   *y_bytes, signs, K, g, strips_x, rows_per_tile, n_tiles, shift);
             else
                 hipLaunchKernelGGL((k_forward_sign_lds<3, true>), gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd,
-                                   *y_bytes, signs, K, g, strips_x, rows_per_tile, n_tiles);
+                                   *y_bytes, signs, K, g, strips_x, rows_per_tile, n_tiles, shift);
         }
         else if (ch == 1)
             hipLaunchKernelGGL((k_forward_sign_lds<1, false>), gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd, y,
-                               signs, K, g, strips_x, rows_per_tile, n_tiles);
+                               signs, K, g, strips_x, rows_per_tile, n_tiles, shift);
         else
             hipLaunchKernelGGL((k_forward_sign_lds<3, false>), gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd, y,
-                               signs, K, g, strips_x, rows_per_tile, n_tiles);
+                               signs, K, g, strips_x, rows_per_tile, n_tiles, shift);
         return check_launch("forward_sign_lds");
     }
     if (g_kernel_path == 0 && scale == 2 && g.n == 5 && generic_plane_stride != 0 && hr_cols >= 8 && hr_rows >= 8 &&
@@ -2893,7 +2929,7 @@ bool backproject_fast_eligible(int hr_rows, int hr_cols, int ch, int scale, cons
 
 int launch_backproject_update(const float* X, float* X_out, int hr_rows, int hr_cols, int ch, const PtrList& raw_fwd,
                               const PtrList* dec_fwd, const PtrList& signs, int K, int scale, const GaussK& g,
-                              const BtvW& w, double tau, double lambda, hipStream_t st)
+                              const BtvW& w, double tau, double lambda, hipStream_t st, int identity_frame)
 {
     if (ch != 1 && ch != 3)
     {
@@ -2911,7 +2947,19 @@ int launch_backproject_update(const float* X, float* X_out, int hr_rows, int hr_
         BtvW ws = w; // twice the weights (exact, checked by backproject_fast_eligible), see half_step2
         for (int i = 0; i < kMaxBtvWeights; ++i)
             ws.w[i] *= 2.0f;
-#define SRX_UPD(CHN, FT) hipLaunchKernelGGL((k_backproject_update_s4<CHN, FT>), gr, b, 0, st, X, X_out, hr_rows, hr_cols, ps, *dec_fwd, signs, K, fw, ws, tau, lambda, tiles_x, n_tiles)
+        // scale 4: a frame vouched to have the identity as its forward map leaves the lists; the kernel works its
+        // entries out by itself and is handed its sign plane separately
+        PtrList maps = *dec_fwd, sgs = signs;
+        const void* still = nullptr;
+        int Kr = K;
+        if (scale == 4 && identity_frame >= 0 && identity_frame < K)
+        {
+            still = signs.p[identity_frame];
+            for (int k = identity_frame; k + 1 < K; ++k)
+                maps.p[k] = dec_fwd->p[k + 1], sgs.p[k] = signs.p[k + 1];
+            Kr = K - 1;
+        }
+#define SRX_UPD(CHN, FT) hipLaunchKernelGGL((k_backproject_update_s4<CHN, FT>), gr, b, 0, st, X, X_out, hr_rows, hr_cols, ps, maps, sgs, Kr, fw, ws, tau, lambda, tiles_x, n_tiles, still)
         if (ch == 1 && scale == 4)
             SRX_UPD(1, 2);
         else if (ch == 1)

@@ -309,6 +309,8 @@ int Solver::run(const float* const* y, const float* const* rel, int K, int base_
 {
     const int announced_bytes = y8_count_; // byte_frames() holds for one call
     y8_count_ = 0;
+    const int still = still_frame_; // set by process() for the call it makes, never by callers of run()
+    still_frame_ = -1;
     if (int rc = validate_params(p))
         return rc;
     if (K < 1 || K > kMaxWindow || base_idx < 0 || base_idx >= K)
@@ -407,13 +409,13 @@ int Solver::run(const float* const* y, const float* const* rel, int K, int base_
         if (time_it)
             SRX_HIP(hipEventRecord(events_[3 * timed], st));
         if (int rc = launch_forward_sign(x_[cur_].as<float>(), (int)R, (int)C, ch, bwd, fastA ? &dbwd : nullptr, ys,
-                                         sgm, K, s, gauss_, ps_, st, have_bytes ? &ys8 : nullptr))
+                                         sgm, K, s, gauss_, ps_, st, have_bytes ? &ys8 : nullptr, still))
             return rc;
         if (time_it)
             SRX_HIP(hipEventRecord(events_[3 * timed + 1], st));
         if (int rc = launch_backproject_update(x_[cur_].as<float>(), x_[cur_ ^ 1].as<float>(), (int)R, (int)C, ch,
                                                fwd, fastB ? &dfwd : nullptr, sg, K, s, gauss_, btv_, p.tau, p.lambda,
-                                               st))
+                                               st, still))
             return rc;
         if (time_it)
         {
@@ -478,6 +480,7 @@ int Solver::process(const float* const* y, const float* const* fwd_motions, int 
     if (int rc = launch_relative_motions(f, r, K, base_idx, (size_t)rows * cols * 2, st))
         return rc;
     forget.armed = false;
+    still_frame_ = base_idx; // k_relative_motions has just written zeros as the base frame's motion
     return run(y, relp, K, base_idx, rows, cols, ch, p, out, x_full, st);
 }
 
