@@ -23,6 +23,14 @@ point before the timed region.  No collective sits on the data path.  `value` is
 `config.span_inclusive` is the rate with every rank's first call (the ring warm-up: r+2 solves on the rank
 that holds the start of the stream, fewer on the others) and the warm-up steps inside the clock.
 
+--scaling strong --frames N (any --gpus): ONE clip of N output frames is cut into contiguous spans by
+srx_span_plan; every rank streams its span from its first call (ring warm-up, the stream's first / last windows
+on the ranks that hold them) to its last output.  `value` = N x Mpix / wall time (max over ranks), so the
+imbalance of the spans and every rank's warm-up are inside it; with --with-single rank 0 first streams the whole
+clip alone and the line carries `efficiency` = T1 / (n Tn).  The boundary frames are posted point to point as
+soon as they exist, the rest of the span is synthesised while they travel, and the wait in front of the first
+call is reported as the exposed halo time.
+
 --workload tvl1 measures the flow stage alone (configs[2]): 1920x1080 grey frame pairs, 5 scales x 5 warps
 x 300 inner iterations at most, pairs sharded over the ranks (independent, no exchange).
 
@@ -77,6 +85,15 @@ def parse():
                     help="do not bracket the solver kernels with HIP events (the roofline object is then left out)")
     ap.add_argument("--cpu-iters", type=int, default=12, help="iterations of the CPU sample solve")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when this process starts the ranks")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: every rank solves --steps frames (the default); strong: one clip of --frames outputs "
+                         "is cut into one span per rank")
+    ap.add_argument("--frames", type=int, default=0, help="outputs of the whole clip (strong scaling); default: "
+                                                         "(steps + warmup) x gpus, at least what the span plan needs")
+    ap.add_argument("--with-single", action="store_true",
+                    help="strong scaling: rank 0 first streams the whole clip alone; the line then carries efficiency")
+    ap.add_argument("--single-ms", type=float, default=0.0,
+                    help="strong scaling: wall time of the same clip on one GPU from an earlier run (for efficiency)")
     a = ap.parse_args()
     if a.workload != "tvl1":
         w = WORKLOADS[a.workload]
@@ -164,6 +181,22 @@ def cpu_baseline(args, lr_u8, flows, base):
 
     threads = oracle.max_threads()
     per_iter, setup, value = measure(args.cpu_iters)
+    # the sample doubles as a parity check at the benchmark's own size: the same window, the same number of
+    # iterations, through the library's default kernels - the two results must be the same bits
+    checked = None
+    if lr_u8[0].is_cuda:
+        import torch
+        from superresolution_amd import api, ops
+
+        p = oracle.BtvParams(scale=args.scale, iterations=1 + args.cpu_iters)
+        want = oracle.btvl1_process(y, fl, base, p)
+        sr = api.BTV_L1(lr_u8[0].device.index)
+        sr.set("scale", args.scale)
+        sr.set("iterations", 1 + args.cpu_iters)
+        got = ops.process_device(sr, [f.to(torch.float32) for f in lr_u8], list(flows), base).cpu().numpy()
+        checked = bool(np.array_equal(want.reshape(got.shape), got))
+        if not checked:
+            raise RuntimeError("cpu_baseline: the oracle's window differs from the GPU's for the same inputs")
     out = {
         "value": value,
         "unit": "Mpix/s",
@@ -171,6 +204,7 @@ def cpu_baseline(args, lr_u8, flows, base):
         "kind": "port",
         "sample": f"one {len(y)}-frame window of the same workload, {1 + args.cpu_iters} solver iterations timed "
                   f"({per_iter:.2f} s/iteration, {setup:.2f} s set-up), scaled to {args.iterations} iterations",
+        "equals_gpu_output": checked,
     }
     if threads > 1 and args.cpu_iters >= 4:
         oracle.set_threads(1)
@@ -411,7 +445,8 @@ def bench_solver(args):
             fwd_launch_s = max(fwd_ms / max(n_it, 1) / 1e3, 1e-12)
             kernels = {}
             # which kernels the library picks for this scale (default parameters otherwise)
-            fwd_name = {4: "k_forward_sign_lds", 2: "k_forward_sign_s2"}.get(s, "k_forward_sign_tile")
+            fwd_name = {4: "k_forward_sign_lds", 2: "k_forward_sign_s2w" if (args.cols * s) % 4 == 0 else "k_forward_sign_s2"}.get(
+                s, "k_forward_sign_tile")
             bwd_name = {4: "k_backproject_update_s4", 2: "k_backproject_update_s4"}.get(s, "k_backproject_update")
             for name, what, nbytes, secs in (
                     (fwd_name, "sign(y_k - D H M_k X) of all window frames", bytes_fwd, fwd_launch_s),
@@ -445,6 +480,172 @@ def bench_solver(args):
             base = min(r, len(frames) - 1)
             win = frames[:2 * r + 1]
             line["cpu_baseline"] = cpu_baseline(args, win, flows[:2 * r], base)
+        print(json.dumps(line), flush=True)
+    R.finish()
+
+
+def _new_handle(args, R, flows_from=None):
+    """A handle set up as the benchmark uses it; flows_from(i) gives the exact motion frame i -> i + 1 of the
+    handle's stream for --flow synthetic and for dry-run handles."""
+    from superresolution_amd import api, _lib as L
+
+    sr = api.BTV_L1(-1 if R.dry else R.local_rank)
+    sr.set("scale", args.scale)
+    sr.set("iterations", args.iterations)
+    sr.set("temporalAreaRadius", args.radius)
+    sr.set("outputMemory", L.SRX_MEM_HOST if args.host_io else L.SRX_MEM_DEVICE)
+    read_ahead = args.flow != "synthetic" and not args.no_read_ahead and not R.dry
+    sr.set("readAhead", 1 if read_ahead else 0)
+    if args.flow == "tvl1" and not R.dry:
+        sr.setOpticalFlow(api.DualTVL1())
+    elif args.flow == "farneback" and not R.dry:
+        sr.setOpticalFlow(api.Farneback())
+    else:
+        counter = {"i": 0}
+
+        def flow_cb(_f0, _f1):
+            f = flows_from(counter["i"])
+            counter["i"] += 1
+            return f.numpy() if R.dry else f
+
+        sr.setOpticalFlow(flow_cb)
+    return sr, read_ahead
+
+
+def bench_strong(args):
+    """Strong scaling: one clip of `frames` outputs, one contiguous span of outputs per rank."""
+    R = Ranks(args)
+    torch = R.torch
+    from superresolution_amd import spans, synth
+
+    r, s = args.radius, args.scale
+    world, rank, dev = R.world, R.rank, R.dev
+    need = world * (2 * r + 1)  # srx_span_plan wants every rank to be fed 2r+1 frames at least
+    total = args.frames if args.frames > 0 else max((args.steps + args.warmup) * world, need)
+    if total < need:
+        print(f"bench.py: --frames {total} is too short for {world} spans of radius {r} (need {need})", file=sys.stderr)
+        sys.exit(2)
+    a, b, in_first, in_last = spans.span_plan(total, r, world, rank)
+    n_own = b - a + 1
+    cams = synth.camera_path(total, seed=1234)
+
+    def frame(t):
+        hr = synth.ground_truth_frame(cams[t], args.rows * s, args.cols * s, args.channels, 1234, dev)
+        return synth.degrade(hr, s)
+
+    def exact_flow(t):
+        return synth.true_forward_flow(cams[t], cams[t + 1], args.rows, args.cols, s, dev)
+
+    def stream_span(left, own, right, first):
+        """All outputs of one span: (seconds, outputs)."""
+        sr, read_ahead = _new_handle(args, R, lambda i: exact_flow(first + i))
+        if args.host_io or R.dry:
+            left, own, right = ([f.cpu().numpy() for f in v] for v in (left, own, right))
+        spans.configure_span(sr, left, own, right)
+        if not R.dry:
+            torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        n_out = 0
+        while sr.nextFrame() is not None:
+            n_out += 1
+        if not R.dry:
+            sr.synchronize()
+        return time.perf_counter() - t0, n_out, read_ahead
+
+    # ---- optional: the whole clip on rank 0 alone (T1), the other ranks idle at the barrier
+    single_s = args.single_ms / 1e3
+    if args.with_single and world > 1:
+        if rank == 0:
+            whole = [frame(t) for t in range(total)]
+            single_s, n_single, _ = stream_span([], whole, [], 0)
+            assert n_single == total
+            del whole
+        R.sync()
+
+    # ---- the span's frames; the boundary frames first, so that they travel while the rest is made
+    R.sync()
+    t_h0 = time.perf_counter()
+    own = [None] * n_own
+    edge = [i for i in range(n_own) if i < r or i >= n_own - r] if world > 1 else []
+    for i in edge:
+        own[i] = frame(a + i)
+    ex = None
+    if world > 1:
+        # HaloExchange reads the first and the last r entries of the list only; the others are made below
+        edges = [f if f is not None else own[0] for f in own]
+        if R.rehearse and not R.dry:
+            edges = [f.cpu() for f in edges]
+        ex = spans.HaloExchange(edges, r, rank, world)
+    for i in range(n_own):
+        if own[i] is None:
+            own[i] = frame(a + i)
+    if not R.dry:
+        torch.cuda.synchronize(dev)
+    t_h1 = time.perf_counter()
+    left, right = ex.wait() if ex else ([], [])
+    if not R.dry:
+        torch.cuda.synchronize(dev)
+    exposed_ms = (time.perf_counter() - t_h1) * 1e3
+    if R.rehearse and not R.dry:
+        left, right = [f.to(dev) for f in left], [f.to(dev) for f in right]
+    assert len(left) == a - in_first and len(right) == in_last - b
+    halo_total_ms = (time.perf_counter() - t_h0) * 1e3
+
+    # ---- timed region: inputs resident, every rank streams its span from its first call to its last output
+    R.sync()
+    t0 = time.perf_counter()
+    own_s, n_out, read_ahead = stream_span(left, own, right, a - len(left))
+    R.sync()
+    elapsed = R.max_over_ranks(time.perf_counter() - t0)
+    assert n_out == n_own, (n_out, n_own)
+    slowest = R.max_over_ranks(own_s)
+    fastest = -R.max_over_ranks(-own_s)
+    exposed_max = R.max_over_ranks(exposed_ms)
+
+    if rank == 0:
+        P = args.rows * s * args.cols * s
+        K = 2 * r + 1
+        mpix = P / 1e6
+        line = {
+            "metric": METRIC,
+            "value": total * mpix / elapsed,
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": total,
+            "warmup": 0,
+            "ms_per_step": elapsed / total * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.config_name}: {args.cols}x{args.rows} {'RGB' if args.channels == 3 else 'gray'} -> "
+                            f"{args.cols * s}x{args.rows * s}, {s}x BTV-L1, {args.iterations} iterations, "
+                            f"temporalAreaRadius {r} (window {K}), one clip of {total} output frames, motion: "
+                            + ("exact synthetic flow (dry run)" if R.dry else
+                               {"tvl1": "built-in TV-L1 flow", "farneback": "built-in Farneback flow"}.get(
+                                   args.flow, "exact synthetic flow resident in HBM")),
+                "frames": total,
+                "partition": "contiguous span of output frames per GPU (srx_span_plan), halo of r LR frames swapped "
+                             "point to point; every rank's ring warm-up and the clip's first and last windows are "
+                             "inside the clock",
+                "frames_per_gpu": {"rank0": n_own, "min": total // world, "max": -(-total // world)},
+                "io": "host frames in, host frames out (PCIe inclusive)" if args.host_io else "frames resident in HBM",
+                "read_ahead": read_ahead,
+                "span_seconds": {"slowest": round(slowest, 4), "fastest": round(fastest, 4)},
+                "halo": {"total_ms": round(halo_total_ms, 3), "exposed_ms": round(exposed_max, 3),
+                         "what": "boundary frames are synthesised first and posted, the rest of the span is synthesised "
+                                 "while they travel; exposed = the wait in front of the first call, max over ranks "
+                                 "(outside `value`, whose clock starts with every input resident in HBM)",
+                         "value_with_exposed_halo": total * mpix / (elapsed + exposed_max / 1e3)},
+            },
+        }
+        if single_s > 0:
+            line["config"]["single_gpu_ms"] = round(single_s * 1e3, 2)
+            line["efficiency"] = single_s / (world * elapsed)
+        if R.rehearse:
+            line["config"]["rehearsal"] = "dry-run handles on CPU over gloo" if R.dry else "all ranks on GPU 0 over gloo"
         print(json.dumps(line), flush=True)
     R.finish()
 
@@ -523,6 +724,8 @@ def bench_tvl1(args):
                 "workload": f"configs[2]: TV-L1 dual optical flow standalone on {cols}x{rows} grey frame pairs, 5 scales x "
                             f"5 warps x 300 inner iterations at most (stops per level and warp at epsilon 0.01)",
                 "partition": "frame pairs sharded over the ranks, no exchange",
+                "pairs_per_gpu": {f"rank{g}": list(spans.pair_shard(R.world * n_pairs, R.world, g))
+                                  for g in range(R.world)},
                 "executed_inner_iterations_per_pair": float(np.mean(iters)),
                 "pixel_iterations_per_pair": float(np.mean(work)),
                 "step_ms": [round(v, 2) for v in step_ms],
@@ -539,15 +742,21 @@ def bench_tvl1(args):
         if R.world == 1 and not args.no_cpu_baseline:
             import oracle.tvl1 as ot
 
-            # bounded sample: the same pair at a quarter of the size in each direction
-            a, b = (g[::4, ::4].contiguous().cpu().numpy() for g in gray[:2])
+            # one pair of the workload at its full size through the scalar C restatement (a few seconds); its flow
+            # and its executed iteration count must be the GPU's
+            a, b = (g.cpu().numpy() for g in gray[:2])
             tc = time.perf_counter()
-            _f, n_it = ot.calc_gray(a, b)
+            ref_flow, n_it = ot.calc_gray(a, b)
             dt = time.perf_counter() - tc
+            got_flow, got_it = sr.calcFlowDevice(gray[0], gray[1])
+            same = bool(np.array_equal(ref_flow, got_flow.cpu().numpy())) and int(got_it) == int(n_it)
+            if not same:
+                raise RuntimeError("cpu_baseline: the oracle's flow differs from the GPU's for the same pair")
             line["cpu_baseline"] = {
-                "value": 1.0 / (dt * 16.0), "unit": "pairs/s", "cores": 1, "kind": "port",
-                "sample": f"one pair decimated to {a.shape[1]}x{a.shape[0]} ({dt:.2f} s, {n_it} inner iterations, scalar "
-                          f"C restatement), scaled by the pixel ratio 16 to the full size"}
+                "value": 1.0 / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+                "sample": f"one {cols}x{rows} pair of the workload ({dt:.2f} s, {n_it} inner iterations, scalar C "
+                          f"restatement)",
+                "equals_gpu_output": same}
         print(json.dumps(line), flush=True)
     R.finish()
 
@@ -558,6 +767,8 @@ def main():
         sys.exit(launch_ranks(args))
     if args.workload == "tvl1":
         bench_tvl1(args)
+    elif args.scaling == "strong":
+        bench_strong(args)
     else:
         bench_solver(args)
 

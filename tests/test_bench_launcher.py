@@ -36,6 +36,30 @@ def test_gpus_2_starts_two_ranks_and_reports_them():
     assert "rehearsal" in d["config"]
 
 
+def test_strong_scaling_cuts_one_clip_into_spans():
+    """--scaling strong: one clip of --frames outputs, a span per rank; every output is delivered once, the line
+    says `strong`, and with --with-single rank 0 streams the whole clip alone first (efficiency = T1 / (n Tn))."""
+    p = _run(["--gpus", "3", "--scaling", "strong", "--frames", "31", "--workload", "cfg1", "--iterations", "2",
+              "--with-single"], SRX_BENCH_REHEARSE="dry")
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _json_line(p.stdout)
+    assert d["n_gpus"] == 3 and d["scaling"] == "strong" and d["steps"] == 31 and d["warmup"] == 0
+    c = d["config"]
+    assert c["frames"] == 31 and c["frames_per_gpu"]["min"] == 10 and c["frames_per_gpu"]["max"] == 11
+    assert c["halo"]["exposed_ms"] >= 0 and c["halo"]["total_ms"] > 0 and c["halo"]["value_with_exposed_halo"] <= d["value"]
+    assert c["single_gpu_ms"] > 0 and 0 < d["efficiency"]
+    assert c["span_seconds"]["slowest"] >= c["span_seconds"]["fastest"] > 0
+    # one rank: the same code path without an exchange
+    p1 = _run(["--gpus", "1", "--scaling", "strong", "--frames", "12", "--workload", "cfg1", "--iterations", "2"],
+              SRX_BENCH_REHEARSE="dry")
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    d1 = _json_line(p1.stdout)
+    assert d1["n_gpus"] == 1 and d1["scaling"] == "strong" and d1["config"]["halo"]["exposed_ms"] >= 0
+    # a clip too short for the spans is refused by every rank before any of them waits for a neighbour
+    p2 = _run(["--gpus", "2", "--scaling", "strong", "--frames", "10", "--workload", "cfg1"], SRX_BENCH_REHEARSE="dry")
+    assert p2.returncode != 0 and "too short" in p2.stderr
+
+
 def test_a_rank_count_other_than_asked_for_is_refused():
     p = _run(["--gpus", "1", "--workload", "cfg1"], SRX_BENCH_REHEARSE="dry", WORLD_SIZE="2", RANK="0")
     assert p.returncode != 0
