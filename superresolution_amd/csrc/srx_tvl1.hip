@@ -81,9 +81,10 @@ int tvl1_set_int(Tvl1Params& p, const std::string& n, int v)
 {
     if (n == "iterationsPerLaunch")
     {
-        if (v != 0 && v != 1 && v != 4 && v != 8)
+        if (v != 0 && v != 1 && v != 4 && v != 8 && v != 12 && v != 14)
         {
-            set_error("flow parameter iterationsPerLaunch must be 0 (by level size), 1, 4 or 8");
+            set_error("flow parameter iterationsPerLaunch must be 0 (by level size), 1, 4 or 8, or 12 / 14 (2 / 4 iterations "
+                      "per launch on whole-line regions)");
             return SRX_ERR_INVALID;
         }
         p.iterationsPerLaunch = v;
@@ -221,9 +222,25 @@ __global__ void k_pyr_down(const float* __restrict__ src, int rows, int cols, fl
     dst[(size_t)y * dc + x] = (r[2] * 6 + (r[1] + r[3]) * 4 + r[0] + r[4]) * 0.00390625f;
 }
 
-__global__ void k_centered_gradient(const float* __restrict__ src, int rows, int cols, float* __restrict__ dx,
-                                    float* __restrict__ dy)
+// All launches of a frame pair are queued without the host looking at anything in between.  The pair is a chain
+// of phases, one per (level, warp); *stop is the first phase that must not run yet because the phase before it
+// has not finished within the launches queued for it (k_phase_gate).  Every kernel of phase `phase` and later
+// then returns at once, which leaves the unfinished phase's state untouched for the host to continue from.
+struct Guard
 {
+    const int* stop;
+    int phase;
+};
+__device__ __forceinline__ bool stopped(const Guard g)
+{
+    return g.stop != nullptr && *g.stop <= g.phase;
+}
+
+__global__ void k_centered_gradient(const float* __restrict__ src, int rows, int cols, float* __restrict__ dx,
+                                    float* __restrict__ dy, Guard guard)
+{
+    if (stopped(guard))
+        return;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= cols || y >= rows)
@@ -249,8 +266,10 @@ __device__ __forceinline__ void cubic_coeffs(float x, float (&c)[4])
 __global__ void k_warp(const float* __restrict__ I0, const float* __restrict__ I1, const float* __restrict__ I1x,
                        const float* __restrict__ I1y, const float* __restrict__ u1, const float* __restrict__ u2,
                        int rows, int cols, float* __restrict__ I1wx, float* __restrict__ I1wy,
-                       float* __restrict__ grad, float* __restrict__ rho_c)
+                       float* __restrict__ grad, float* __restrict__ rho_c, Guard guard)
 {
+    if (stopped(guard))
+        return;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= cols || y >= rows)
@@ -360,9 +379,9 @@ __device__ __forceinline__ void tvl1_new_u(const Tvl1Planes& P, int x, int y, in
 
 __global__ __launch_bounds__(256) void k_tvl1_iter(Tvl1Planes P, int rows, int cols, float l_t, float theta, float taut,
                                                     unsigned long long* __restrict__ err, int it,
-                                                    unsigned long long thr)
+                                                    unsigned long long thr, Guard guard)
 {
-    if (it > 0 && err[it - 1] <= thr)
+    if (stopped(guard) || (it > 0 && err[it - 1] <= thr))
         return;
     __shared__ float su1[(kItY + 1) * (kItX + 1)], su2[(kItY + 1) * (kItX + 1)];
     __shared__ unsigned long long part[4];
@@ -462,9 +481,9 @@ __device__ __forceinline__ void tvl1_u_values(float gx, float gy, float g, float
 
 __global__ __launch_bounds__(32 * (kIt4Y + 2)) void k_tvl1_iter4(Tvl1Planes P, int rows, int cols, float l_t, float theta,
                                                      float taut, unsigned long long* __restrict__ err, int it,
-                                                     unsigned long long thr)
+                                                     unsigned long long thr, Guard guard)
 {
-    if (it > 0 && err[it - 1] <= thr)
+    if (stopped(guard) || (it > 0 && err[it - 1] <= thr))
         return;
     __shared__ __attribute__((aligned(16))) float su1[(kIt4Y + 1) * kIt4Pitch], su2[(kIt4Y + 1) * kIt4Pitch];
     __shared__ unsigned long long part[(kIt4Y + 2) / 2];
@@ -606,8 +625,10 @@ __global__ __launch_bounds__(32 * (kIt4Y + 2)) void k_tvl1_iter4(Tvl1Planes P, i
 template <int KT, int TW, int TH, int NT>
 __global__ __launch_bounds__(NT, NT == 256 ? 4 : 4) void k_tvl1_multi(Tvl1Planes P, int rows, int cols, float l_t, float theta,
                                                      float taut, unsigned long long* __restrict__ err, int n_err,
-                                                     int it0, int n_iter, unsigned long long thr)
+                                                     int it0, int n_iter, unsigned long long thr, Guard guard)
 {
+    if (stopped(guard))
+        return;
     constexpr int RW = TW + 2 * KT, RH = TH + 2 * KT, CELLS = RW * RH, PER = (CELLS + NT - 1) / NT;
     __shared__ float s_p11[CELLS], s_p21[CELLS], s_p12[CELLS], s_p22[CELLS], s_u1[CELLS], s_u2[CELLS];
     __shared__ unsigned long long s_err[KT][NT / 64];
@@ -765,10 +786,249 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 4) void k_tvl1_multi(Tvl1Planes
     }
 }
 
+// value held by lane-1 / lane+1 of the wave (0 at the wave's ends)
+__device__ __forceinline__ float lane_left(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_right(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xF, 0xF, true));
+}
+
+// Several inner iterations in one launch on regions whose rows are whole 512-byte runs of every plane: the form
+// of k_tvl1_multi for levels whose width is a multiple of 4 (all planes are then 16-byte aligned row by row).
+//   region: kRowsW = 128 columns (a tile of kRowsTW = 120 columns with 4 columns of halo on either side, so that
+//   a region starts at a multiple of 4 floats) x RR = (NT / 32) * RPT rows (a tile of RR - 2 KT rows with KT rows
+//   of halo above and below);
+//   a thread owns four neighbouring pixels of RPT neighbouring rows and keeps their state (the warp's four
+//   constants, u, p) in registers for the whole launch: one 16-byte load per plane, row and thread going in,
+//   one 16-byte store per plane coming out;
+//   neighbours: the pixels left and right of a thread's four are in the neighbouring lanes (a row is 32 lanes;
+//   what the first and last lane of a row get from the other row of their wave only ever reaches the region's
+//   outermost ring), the rows above and below a thread's rows go through LDS, one row per thread and direction.
+// As in k_tvl1_multi every iteration makes the outermost ring of the region wrong by one more pixel and leaves
+// the tile exact after KT iterations; every value of the tile is computed by the same operations from the same
+// operands as by one launch per iteration.  The launch protocol (which iterations a launch covers, what it does
+// once an earlier iteration has met the threshold) is that of k_tvl1_multi.
+constexpr int kRowsW = 128, kRowsTW = 120, kRowsHX = 4;
+template <int KT, int RPT, int NT>
+__global__ __launch_bounds__(NT, 4) void k_tvl1_rows(Tvl1Planes P, int rows, int cols, float l_t, float theta, float taut,
+                                                   unsigned long long* __restrict__ err, int n_err, int it0, int n_iter,
+                                                   unsigned long long thr, Guard guard)
+{
+    if (stopped(guard))
+        return;
+    constexpr int TR = NT / 32;       // rows of threads
+    constexpr int RR = TR * RPT;      // rows of the region
+    constexpr int TH = RR - 2 * KT;   // rows of the tile
+    static_assert(KT <= kRowsHX && TH > 0 && NT % 64 == 0, "halo and block shape");
+    // what the thread row below / above needs of this thread row: p12, p22 of its last row, the new u of its first
+    __shared__ __attribute__((aligned(16))) float s_p12[TR * kRowsW], s_p22[TR * kRowsW], s_n1[TR * kRowsW], s_n2[TR * kRowsW];
+    __shared__ unsigned long long s_err[KT][NT / 64];
+    __shared__ int s_first;
+    const int tid = threadIdx.x;
+    if (tid < 64)
+    {
+        int first = 0x7FFFFFFF;
+        for (int j = tid; j < min(it0, n_err); j += 64) // err[] has n_err entries
+            if (err[j] <= thr)
+            {
+                first = j;
+                break;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            first = min(first, __shfl_down(first, o, 64));
+        if (tid == 0)
+            s_first = first;
+    }
+    __syncthreads();
+    const int first = s_first;
+    bool redo = false;
+    if (first != 0x7FFFFFFF)
+    {
+        if (first < it0 - KT || first == it0 - 1)
+            return;
+        redo = true;
+        n_iter = first - (it0 - KT) + 1;
+    }
+    const float* ru1 = redo ? P.nu1 : P.u1;
+    const float* ru2 = redo ? P.nu2 : P.u2;
+    const float* rp11 = redo ? P.np11 : P.p11;
+    const float* rp12 = redo ? P.np12 : P.p12;
+    const float* rp21 = redo ? P.np21 : P.p21;
+    const float* rp22 = redo ? P.np22 : P.p22;
+    float* wu1 = redo ? const_cast<float*>(P.u1) : P.nu1;
+    float* wu2 = redo ? const_cast<float*>(P.u2) : P.nu2;
+    float* wp11 = redo ? const_cast<float*>(P.p11) : P.np11;
+    float* wp12 = redo ? const_cast<float*>(P.p12) : P.np12;
+    float* wp21 = redo ? const_cast<float*>(P.p21) : P.np21;
+    float* wp22 = redo ? const_cast<float*>(P.p22) : P.np22;
+
+    const int lx = tid & 31, tr = tid >> 5;
+    const int gx0 = (int)blockIdx.x * kRowsTW - kRowsHX + 4 * lx; // image column of the thread's first pixel
+    const int gy0 = (int)blockIdx.y * TH - KT + tr * RPT;         // image row of the thread's first row
+    const bool col_in = gx0 >= 0 && gx0 < cols;                   // cols % 4 == 0: four pixels are in or out together
+    float cgx[RPT][4], cgy[RPT][4], cg[RPT][4], crc[RPT][4], a[RPT][4], b[RPT][4];
+    float q11[RPT][4], q12[RPT][4], q21[RPT][4], q22[RPT][4];
+    bool inside[RPT];
+    auto spread = [](const float4 v, float (&d)[4]) { d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w; };
+#pragma unroll
+    for (int i = 0; i < RPT; ++i)
+    {
+        const int gy = gy0 + i;
+        inside[i] = col_in && gy >= 0 && gy < rows;
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v[10] = {z, z, z, z, z, z, z, z, z, z};
+        if (inside[i])
+        {
+            const size_t o = (size_t)gy * cols + gx0;
+            v[0] = *(const float4*)(P.I1wx + o), v[1] = *(const float4*)(P.I1wy + o);
+            v[2] = *(const float4*)(P.grad + o), v[3] = *(const float4*)(P.rho_c + o);
+            v[4] = *(const float4*)(ru1 + o), v[5] = *(const float4*)(ru2 + o);
+            v[6] = *(const float4*)(rp11 + o), v[7] = *(const float4*)(rp12 + o);
+            v[8] = *(const float4*)(rp21 + o), v[9] = *(const float4*)(rp22 + o);
+        }
+        spread(v[0], cgx[i]), spread(v[1], cgy[i]), spread(v[2], cg[i]), spread(v[3], crc[i]);
+        spread(v[4], a[i]), spread(v[5], b[i]);
+        spread(v[6], q11[i]), spread(v[7], q12[i]), spread(v[8], q21[i]), spread(v[9], q22[i]);
+    }
+    const int srow = tr * kRowsW + 4 * lx; // this thread's place in the exchange rows
+    *(float4*)&s_p12[srow] = make_float4(q12[RPT - 1][0], q12[RPT - 1][1], q12[RPT - 1][2], q12[RPT - 1][3]);
+    *(float4*)&s_p22[srow] = make_float4(q22[RPT - 1][0], q22[RPT - 1][1], q22[RPT - 1][2], q22[RPT - 1][3]);
+    unsigned long long e[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+        e[j] = 0;
+    // which of the thread's pixels belong to the tile (the error is summed over tiles, the stores cover them)
+    const bool tile_col = lx >= 1 && lx <= 30;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+    {
+        if (j < n_iter) // the same for every thread of the block
+        {
+            // p12, p22 of the row above the thread's first row
+            float4 up12 = make_float4(0.f, 0.f, 0.f, 0.f), up22 = up12;
+            if (tr > 0)
+            {
+                up12 = *(const float4*)&s_p12[srow - kRowsW];
+                up22 = *(const float4*)&s_p22[srow - kRowsW];
+            }
+            float u12[4], u22[4];
+            spread(up12, u12), spread(up22, u22);
+#pragma unroll
+            for (int i = 0; i < RPT; ++i)
+            {
+                const int gy = gy0 + i;
+                const float l11 = lane_left(q11[i][3]), l21 = lane_left(q21[i][3]);
+                float n1[4], n2[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    tvl1_u_values(cgx[i][k], cgy[i][k], cg[i][k], crc[i][k], a[i][k], b[i][k], q11[i][k], q12[i][k], q21[i][k],
+                                  q22[i][k], k == 0 ? l11 : q11[i][k - 1], k == 0 ? l21 : q21[i][k - 1],
+                                  i == 0 ? u12[k] : q12[i - 1][k], i == 0 ? u22[k] : q22[i - 1][k], gx0 + k > 0, gy > 0, l_t,
+                                  theta, n1[k], n2[k]);
+                const int cy = tr * RPT + i;
+                if (inside[i] && tile_col && cy >= KT && cy < KT + TH)
+                {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        e[j] += error_term(n1[k] - a[i][k], n2[k] - b[i][k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    a[i][k] = n1[k], b[i][k] = n2[k];
+            }
+            *(float4*)&s_n1[srow] = make_float4(a[0][0], a[0][1], a[0][2], a[0][3]);
+            *(float4*)&s_n2[srow] = make_float4(b[0][0], b[0][1], b[0][2], b[0][3]);
+        }
+        __syncthreads();
+        if (j < n_iter)
+        {
+            // new u of the row below the thread's last row
+            float4 dn1 = make_float4(0.f, 0.f, 0.f, 0.f), dn2 = dn1;
+            if (tr + 1 < TR)
+            {
+                dn1 = *(const float4*)&s_n1[srow + kRowsW];
+                dn2 = *(const float4*)&s_n2[srow + kRowsW];
+            }
+            float d1v[4], d2v[4];
+            spread(dn1, d1v), spread(dn2, d2v);
+#pragma unroll
+            for (int i = 0; i < RPT; ++i)
+            {
+                const int gy = gy0 + i;
+                const bool has_d = gy < rows - 1;
+                const float r1e = lane_right(a[i][0]), r2e = lane_right(b[i][0]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                {
+                    const bool has_r = gx0 + k < cols - 1;
+                    const float n1 = a[i][k], n2 = b[i][k];
+                    const float r1 = k < 3 ? a[i][k < 3 ? k + 1 : 3] : r1e, r2 = k < 3 ? b[i][k < 3 ? k + 1 : 3] : r2e;
+                    const float d1 = i + 1 < RPT ? a[i + 1 < RPT ? i + 1 : i][k] : d1v[k];
+                    const float d2 = i + 1 < RPT ? b[i + 1 < RPT ? i + 1 : i][k] : d2v[k];
+                    const float u1x = has_r ? r1 - n1 : 0.0f, u1y = has_d ? d1 - n1 : 0.0f;
+                    const float u2x = has_r ? r2 - n2 : 0.0f, u2y = has_d ? d2 - n2 : 0.0f;
+                    const float g1 = sqrtf(u1x * u1x + u1y * u1y), g2 = sqrtf(u2x * u2x + u2y * u2y);
+                    const float ng1 = 1.0f + taut * g1, ng2 = 1.0f + taut * g2;
+                    q11[i][k] = (q11[i][k] + taut * u1x) / ng1;
+                    q12[i][k] = (q12[i][k] + taut * u1y) / ng1;
+                    q21[i][k] = (q21[i][k] + taut * u2x) / ng2;
+                    q22[i][k] = (q22[i][k] + taut * u2y) / ng2;
+                }
+            }
+            *(float4*)&s_p12[srow] = make_float4(q12[RPT - 1][0], q12[RPT - 1][1], q12[RPT - 1][2], q12[RPT - 1][3]);
+            *(float4*)&s_p22[srow] = make_float4(q22[RPT - 1][0], q22[RPT - 1][1], q22[RPT - 1][2], q22[RPT - 1][3]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i)
+    {
+        const int cy = tr * RPT + i;
+        if (inside[i] && tile_col && cy >= KT && cy < KT + TH)
+        {
+            const size_t o = (size_t)(gy0 + i) * cols + gx0;
+            *(float4*)(wu1 + o) = make_float4(a[i][0], a[i][1], a[i][2], a[i][3]);
+            *(float4*)(wu2 + o) = make_float4(b[i][0], b[i][1], b[i][2], b[i][3]);
+            *(float4*)(wp11 + o) = make_float4(q11[i][0], q11[i][1], q11[i][2], q11[i][3]);
+            *(float4*)(wp12 + o) = make_float4(q12[i][0], q12[i][1], q12[i][2], q12[i][3]);
+            *(float4*)(wp21 + o) = make_float4(q21[i][0], q21[i][1], q21[i][2], q21[i][3]);
+            *(float4*)(wp22 + o) = make_float4(q22[i][0], q22[i][1], q22[i][2], q22[i][3]);
+        }
+    }
+    if (redo)
+        return;
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+    {
+        unsigned long long v = e[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            v += __shfl_down(v, o, 64);
+        if ((tid & 63) == 0)
+            s_err[j][tid >> 6] = v;
+    }
+    __syncthreads();
+    if (tid < KT && tid < n_iter)
+    {
+        unsigned long long sum = 0;
+#pragma unroll
+        for (int wv = 0; wv < NT / 64; ++wv)
+            sum += s_err[tid][wv];
+        atomicAdd(&err[it0 + tid], sum);
+    }
+}
+
 // cv::resize(INTER_LINEAR) of the two flow planes to the next finer level, times 2
 __global__ void k_upsample_flow(const float* __restrict__ s1, const float* __restrict__ s2, int srows, int scols,
-                                float* __restrict__ d1, float* __restrict__ d2, int drows, int dcols)
+                                float* __restrict__ d1, float* __restrict__ d2, int drows, int dcols, Guard guard)
 {
+    if (stopped(guard))
+        return;
     const int dx = blockIdx.x * blockDim.x + threadIdx.x;
     const int dy = blockIdx.y * blockDim.y + threadIdx.y;
     if (dx >= dcols || dy >= drows)
@@ -805,6 +1065,96 @@ __global__ void k_upsample_flow(const float* __restrict__ s1, const float* __res
     }
 }
 
+// First iteration of a phase whose error is at most thr, looked for by one wave; 0x7FFFFFFF if there is none
+// among the first `n` entries.
+__device__ __forceinline__ int first_converged(const unsigned long long* __restrict__ err, int n, unsigned long long thr,
+                                               int lane)
+{
+    int first = 0x7FFFFFFF;
+    for (int j = lane; j < n; j += 64)
+        if (err[j] <= thr)
+        {
+            first = j;
+            break;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        first = min(first, __shfl_xor(first, o, 64));
+    return first;
+}
+
+// Has the phase before `phase` finished within the n_enq launches of kt iterations queued for it?  It has when
+// an iteration met the threshold and the launch that holds it either ended with it or is followed by another
+// queued launch (which repairs the overrun), or when all `iters` iterations were queued and none met it.
+// Otherwise *stop becomes `phase` (unless an earlier phase already stopped the chain).  One wave.
+__global__ void k_phase_gate(const unsigned long long* __restrict__ err_prev, int n_enq, int kt, int iters,
+                             unsigned long long thr, int* __restrict__ stop, int phase)
+{
+    if (*stop <= phase)
+        return;
+    const int queued = min(n_enq * kt, iters);
+    const int first = first_converged(err_prev, queued, thr, (int)threadIdx.x);
+    bool complete;
+    if (first == 0x7FFFFFFF)
+        complete = queued >= iters;
+    else
+        complete = first % kt == kt - 1 || first == iters - 1 || first / kt + 1 < n_enq;
+    if (!complete && threadIdx.x == 0)
+        *stop = phase;
+}
+
+// A finished phase leaves its result in the buffer set its last launch wrote: set (last_launch + 1) & 1.  The next
+// phase reads set 0, so a result in set 1 is copied over (u: 2 planes of n, p: 4 planes of n, contiguous).
+__global__ __launch_bounds__(256) void k_settle(const unsigned long long* __restrict__ err, int kt, int iters,
+                                                 unsigned long long thr, float* __restrict__ u1, float* __restrict__ u2,
+                                                 const float* __restrict__ u_alt, float* __restrict__ p,
+                                                 const float* __restrict__ p_alt, size_t n, Guard guard)
+{
+    if (stopped(guard))
+        return;
+    __shared__ int s_first;
+    if (threadIdx.x < 64)
+    {
+        const int f = first_converged(err, iters, thr, (int)threadIdx.x);
+        if (threadIdx.x == 0)
+            s_first = f;
+    }
+    __syncthreads();
+    const int done = s_first == 0x7FFFFFFF ? iters : s_first + 1;
+    const int last_launch = (done - 1) / kt;
+    if (((last_launch + 1) & 1) == 0)
+        return;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 6 * n; i += stride)
+    {
+        if (i < n)
+            u1[i] = u_alt[i];
+        else if (i < 2 * n)
+            u2[i - n] = u_alt[i];
+        else
+            p[i - 2 * n] = p_alt[i - 2 * n];
+    }
+}
+
+__global__ void k_zero_guarded(float* __restrict__ dst, size_t count, Guard guard)
+{
+    if (stopped(guard))
+        return;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+        dst[i] = 0.0f;
+}
+
+__global__ void k_merge2_guarded(const float* __restrict__ u, const float* __restrict__ v, size_t count,
+                                 float2* __restrict__ uv, Guard guard)
+{
+    if (stopped(guard))
+        return;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count)
+        uv[i] = make_float2(u[i], v[i]);
+}
+
 inline dim3 grid2(int cols, int rows, dim3 b)
 {
     return dim3((cols + b.x - 1) / b.x, (rows + b.y - 1) / b.y);
@@ -817,6 +1167,27 @@ inline dim3 grid2(int cols, int rows, dim3 b)
         if (e__ != hipSuccess)                                                                                         \
             return hip_fail(e__, what);                                                                                \
     } while (0)
+
+// k_tvl1_rows: iterations per launch and threads per block for levels above / up to a megapixel.  Tuning aids:
+// SRX_TVL1_ROWS="kt_big,nt_big,kt_mid,nt_mid" in the environment replaces them (read once).
+int g_rows_kt_big = 2, g_rows_nt_big = 512, g_rows_kt_mid = 4, g_rows_nt_mid = 512;
+// launches queued for a phase beyond what the previous pair needed: max(min, need / div); SRX_TVL1_MARGIN="min,div"
+int g_chain_margin_min = 3, g_chain_margin_div = 3;
+const bool g_rows_env = [] {
+    if (const char* e = std::getenv("SRX_TVL1_ROWS"))
+    {
+        int v[4];
+        if (std::sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4)
+            g_rows_kt_big = v[0], g_rows_nt_big = v[1], g_rows_kt_mid = v[2], g_rows_nt_mid = v[3];
+    }
+    if (const char* e = std::getenv("SRX_TVL1_MARGIN"))
+    {
+        int a = 0, b = 0;
+        if (std::sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 1)
+            g_chain_margin_min = a, g_chain_margin_div = b;
+    }
+    return true;
+}();
 
 constexpr int kMaxScales = 16;
 constexpr int kPollStride = 32; // most inner iterations enqueued before the first look at the error
@@ -847,7 +1218,7 @@ struct Tvl1::Impl
     // inner iterations each (level, warp) ran in the previous call: consecutive frame pairs of a stream converge
     // alike, so this sizes the first batch of launches (results do not depend on it, only the number of
     // launches that find the iteration already converged)
-    std::vector<int> last_done;
+    std::vector<int> last_done, before_last_done;
     long long pixel_iterations = 0; // sum over (level, warp) of pixels x executed inner iterations, last call
 };
 
@@ -950,145 +1321,234 @@ int Tvl1::calc_gray(const float* I0, const float* I1, int rows, int cols, const 
     if (int rc = m.u_alt.reserve(2 * px0 * sizeof(float)))
         return rc;
     const int iters = std::max(p.iterations, 1);
-    if (int rc = m.err.reserve((size_t)iters * sizeof(unsigned long long)))
+    const int n_phases = nscales * p.warps;
+    // one error array per phase, and behind them the word that stops the chain (see Guard)
+    const size_t err_words = (size_t)n_phases * iters;
+    if (int rc = m.err.reserve((err_words + 1) * sizeof(unsigned long long)))
         return rc;
-    if (int rc = m.host_err.reserve((size_t)iters * sizeof(unsigned long long)))
+    if (int rc = m.host_err.reserve((err_words + 1) * sizeof(unsigned long long)))
         return rc;
-    unsigned long long* herr = (unsigned long long*)m.host_err.get();
+    unsigned long long* const derr = m.err.as<unsigned long long>();
+    int* const dstop = (int*)(derr + err_words);
+    const unsigned long long* const herr = (const unsigned long long*)m.host_err.get();
+    const int* const hstop = (const int*)(herr + err_words);
 
-    if (m.last_done.size() != (size_t)nscales * p.warps)
-        m.last_done.assign((size_t)nscales * p.warps, kPollStride - 1);
+    if (m.last_done.size() != (size_t)n_phases)
+    {
+        m.last_done.assign((size_t)n_phases, kPollStride - 1);
+        m.before_last_done.assign((size_t)n_phases, 0);
+    }
     const float l_t = (float)(p.lambda * p.theta), taut = (float)(p.tau / p.theta), theta = (float)p.theta;
-    long long executed = 0;
-    m.pixel_iterations = 0;
+
+    // ---- the plan: one phase per (level, warp), coarsest level first
+    struct Phase
+    {
+        int s, w, R, C, kernel, kt, rows_nt, n_launch, n_enq;
+        size_t n;
+        unsigned long long thr;
+        unsigned long long* err;
+    };
+    std::vector<Phase> plan((size_t)n_phases);
+    for (int s = nscales - 1, k = 0; s >= 0; --s)
+        for (int w = 0; w < p.warps; ++w, ++k)
+        {
+            Phase& ph = plan[(size_t)k];
+            ph.s = s, ph.w = w, ph.R = m.lv[s].rows, ph.C = m.lv[s].cols;
+            ph.n = (size_t)ph.R * ph.C;
+            const float scaled_eps = (float)(p.epsilon * p.epsilon * (double)ph.n);
+            ph.thr = (unsigned long long)((double)scaled_eps * 1073741824.0);
+            ph.err = derr + (size_t)k * iters;
+            // 0: at most 200 000 pixels, 1: at most 1 000 000, 2: more
+            const int by_size = ph.n > (size_t)1000000 ? 2 : (ph.n > (size_t)200000 ? 1 : 0);
+            // Iterations per launch.  Small levels are bound by the time a launch takes whatever it does: 8 iterations
+            // on tiles of 16 x 16.  Larger levels are bound by memory traffic: where the width is a multiple of 4 they
+            // run several iterations per launch on regions of whole 512-byte rows (k_tvl1_rows), which reads and
+            // writes every plane once per launch; other widths fall back to 32 x 32 tiles (up to a megapixel) and to
+            // one iteration per launch (above: the short row segments of a tile with halo waste too much of every
+            // cache line there).
+            const bool wide = ph.C % 4 == 0;
+            // kernel: 0 k_tvl1_multi<8,16,16>, 1 k_tvl1_multi<4,32,32>, 2 one iteration per launch, 3 k_tvl1_rows
+            ph.kernel = p.iterationsPerLaunch == 1 ? 2 : p.iterationsPerLaunch == 4 ? 1 : p.iterationsPerLaunch == 8 ? 0
+                        : (p.iterationsPerLaunch == 12 || p.iterationsPerLaunch == 14) ? (wide ? 3 : 1)
+                        : (by_size >= 1 && wide ? 3 : by_size);
+            const int rows_kt = p.iterationsPerLaunch == 12 ? 2 : p.iterationsPerLaunch == 14 ? 4
+                                : (by_size == 2 ? g_rows_kt_big : g_rows_kt_mid);
+            ph.rows_nt = by_size == 2 ? g_rows_nt_big : g_rows_nt_mid;
+            ph.kt = ph.kernel == 3 ? rows_kt : ph.kernel == 2 ? 1 : (ph.kernel == 1 ? 4 : 8);
+            ph.n_launch = (iters + ph.kt - 1) / ph.kt;
+            ph.n_enq = 0;
+        }
+
+    auto launch_iterations = [&](const Phase& ph, int k, int bidx) {
+        Impl::Level& L = m.lv[ph.s];
+        const size_t n = ph.n;
+        const int R = ph.R, C = ph.C, kt = ph.kt;
+        float* ua[2][2] = {{L.u1.as<float>(), L.u2.as<float>()}, {m.u_alt.as<float>(), m.u_alt.as<float>() + n}};
+        float* pa[2] = {m.p.as<float>(), m.p_alt.as<float>()};
+        const int src = bidx & 1, dst = src ^ 1;
+        Tvl1Planes P;
+        P.I1wx = m.I1wx.as<float>(), P.I1wy = m.I1wy.as<float>(), P.grad = m.grad.as<float>();
+        P.rho_c = m.rho_c.as<float>();
+        P.u1 = ua[src][0], P.u2 = ua[src][1];
+        P.p11 = pa[src], P.p12 = pa[src] + n, P.p21 = pa[src] + 2 * n, P.p22 = pa[src] + 3 * n;
+        P.nu1 = ua[dst][0], P.nu2 = ua[dst][1];
+        P.np11 = pa[dst], P.np12 = pa[dst] + n, P.np21 = pa[dst] + 2 * n, P.np22 = pa[dst] + 3 * n;
+        const Guard g{dstop, k};
+        // (a launch past the last iteration only ever repairs the one before it)
+        const int first = bidx * kt, count = std::max(0, std::min(kt, iters - first));
+        const int tw = ph.kernel == 0 ? 16 : 32, th = tw;
+        const dim3 gm((C + tw - 1) / tw, (R + th - 1) / th);
+        if (ph.kernel == 2) // one iteration per launch: launch `bidx` is iteration `bidx`
+        {
+            if (C % 4 == 0)
+                hipLaunchKernelGGL(k_tvl1_iter4, grid2(C, R, dim3(kIt4X, kIt4Y)), dim3(32, kIt4Y + 2), 0, st, P, R, C, l_t,
+                                   theta, taut, ph.err, bidx, ph.thr, g);
+            else
+                hipLaunchKernelGGL(k_tvl1_iter, grid2(C, R, dim3(kItX, kItY)), dim3(kItX, kItY), 0, st, P, R, C, l_t, theta,
+                                   taut, ph.err, bidx, ph.thr, g);
+        }
+        else if (ph.kernel == 3)
+        {
+#define SRX_ROWS(KTV, RPTV, NTV)                                                                                       \
+    hipLaunchKernelGGL((k_tvl1_rows<KTV, RPTV, NTV>),                                                                  \
+                       dim3((C + kRowsTW - 1) / kRowsTW, (R + (NTV / 32 * RPTV - 2 * KTV) - 1) / (NTV / 32 * RPTV - 2 * KTV)), \
+                       dim3(NTV), 0, st, P, R, C, l_t, theta, taut, ph.err, iters, first, count, ph.thr, g)
+            if (kt == 2 && ph.rows_nt == 256)
+                SRX_ROWS(2, 2, 256);
+            else if (kt == 2 && ph.rows_nt == 512)
+                SRX_ROWS(2, 2, 512);
+            else if (kt == 2)
+                SRX_ROWS(2, 2, 1024);
+            else if (ph.rows_nt == 256)
+                SRX_ROWS(4, 2, 256);
+            else if (ph.rows_nt == 512)
+                SRX_ROWS(4, 2, 512);
+            else
+                SRX_ROWS(4, 2, 1024);
+#undef SRX_ROWS
+        }
+        else if (ph.kernel == 1)
+            hipLaunchKernelGGL((k_tvl1_multi<4, 32, 32, 256>), gm, dim3(256), 0, st, P, R, C, l_t, theta, taut, ph.err, iters,
+                               first, count, ph.thr, g);
+        else
+            hipLaunchKernelGGL((k_tvl1_multi<8, 16, 16, 1024>), gm, dim3(1024), 0, st, P, R, C, l_t, theta, taut, ph.err,
+                               iters, first, count, ph.thr, g);
+    };
+    // what stands between phase k - 1 and phase k: the gate, the settling of phase k - 1's result into buffer set 0
+    // and, at the first warp of a level, the flow of the level before brought up to this one
+    auto launch_between = [&](int k) {
+        const Phase& prev = plan[(size_t)k - 1];
+        Impl::Level& L = m.lv[prev.s];
+        hipLaunchKernelGGL(k_phase_gate, dim3(1), dim3(64), 0, st, prev.err, prev.n_enq, prev.kt, iters, prev.thr, dstop, k);
+        const Guard g{dstop, k};
+        const unsigned blocks = (unsigned)std::min<size_t>((6 * prev.n + 255) / 256, 2048);
+        hipLaunchKernelGGL(k_settle, dim3(blocks), dim3(256), 0, st, prev.err, prev.kt, iters, prev.thr, L.u1.as<float>(),
+                           L.u2.as<float>(), m.u_alt.as<float>(), m.p.as<float>(), m.p_alt.as<float>(), prev.n, g);
+        if (k == n_phases)
+        {
+            hipLaunchKernelGGL(k_merge2_guarded, dim3((unsigned)((px0 + 255) / 256)), dim3(256), 0, st, m.lv[0].u1.as<float>(),
+                               m.lv[0].u2.as<float>(), px0, (float2*)flow_uv, g);
+            return;
+        }
+        if (plan[(size_t)k].w == 0)
+        {
+            Impl::Level& F = m.lv[plan[(size_t)k].s];
+            hipLaunchKernelGGL(k_upsample_flow, grid2(F.cols, F.rows, b2), b2, 0, st, L.u1.as<float>(), L.u2.as<float>(), L.rows,
+                               L.cols, F.u1.as<float>(), F.u2.as<float>(), F.rows, F.cols, g);
+        }
+    };
+    // what opens phase k: at the first warp of a level the gradient of I1 and p = 0, then the warp
+    auto launch_opening = [&](int k) {
+        const Phase& ph = plan[(size_t)k];
+        Impl::Level& L = m.lv[ph.s];
+        const Guard g{dstop, k};
+        const dim3 g2 = grid2(ph.C, ph.R, b2);
+        if (ph.w == 0)
+        {
+            hipLaunchKernelGGL(k_centered_gradient, g2, b2, 0, st, L.I1.as<float>(), ph.R, ph.C, m.I1x.as<float>(),
+                               m.I1y.as<float>(), g);
+            const unsigned blocks = (unsigned)std::min<size_t>((4 * ph.n + 255) / 256, 2048);
+            hipLaunchKernelGGL(k_zero_guarded, dim3(blocks), dim3(256), 0, st, m.p.as<float>(), 4 * ph.n, g);
+        }
+        hipLaunchKernelGGL(k_warp, g2, b2, 0, st, L.I0.as<float>(), L.I1.as<float>(), m.I1x.as<float>(), m.I1y.as<float>(),
+                           L.u1.as<float>(), L.u2.as<float>(), ph.R, ph.C, m.I1wx.as<float>(), m.I1wy.as<float>(),
+                           m.grad.as<float>(), m.rho_c.as<float>(), g);
+    };
+
+    SRX_HIP(hipMemsetAsync(derr, 0, (err_words + 1) * sizeof(unsigned long long), st));
     {
         const size_t n = (size_t)m.lv[nscales - 1].rows * m.lv[nscales - 1].cols * sizeof(float);
         SRX_HIP(hipMemsetAsync(m.lv[nscales - 1].u1.get(), 0, n, st));
         SRX_HIP(hipMemsetAsync(m.lv[nscales - 1].u2.get(), 0, n, st));
     }
-    for (int s = nscales - 1; s >= 0; --s)
+    // Launches of a phase queued at first: what the same phase of the previous pair needed (consecutive pairs of a
+    // stream converge alike) and a margin; launches queued beyond the converged iteration return at once.  The host
+    // looks once, behind the whole chain; a chain that stopped at some phase is continued from there.
+    // launch n_launch of a kernel of several iterations only ever repairs an overrun of the launch before it; a
+    // kernel of one iteration per launch has no such launch (and would write behind its error array)
+    auto launch_cap = [](const Phase& ph) { return ph.n_launch + (ph.kt > 1 ? 1 : 0); };
+    auto first_batch = [&](const Phase& ph, int predicted) {
+        const int need = (std::max(predicted, 1) + ph.kt - 1) / ph.kt;
+        return std::min(launch_cap(ph), need + std::max(g_chain_margin_min, need / g_chain_margin_div));
+    };
+    int resume = 0;         // first phase whose opening has not been queued yet
+    int unfinished = -1;    // phase that has to go on before `resume` (its opening is done), or -1
+    for (int round = 0;; ++round)
     {
-        Impl::Level& L = m.lv[s];
-        const int R = L.rows, C = L.cols;
-        const size_t n = (size_t)R * C;
-        const dim3 g2 = grid2(C, R, b2);
-        float* p11 = m.p.as<float>();
-        hipLaunchKernelGGL(k_centered_gradient, g2, b2, 0, st, L.I1.as<float>(), R, C, m.I1x.as<float>(),
-                           m.I1y.as<float>());
-        SRX_LAUNCH_CHECK("centered_gradient");
-        SRX_HIP(hipMemsetAsync(p11, 0, 4 * n * sizeof(float), st));
-        const float scaled_eps = (float)(p.epsilon * p.epsilon * (double)n);
-        const unsigned long long thr = (unsigned long long)((double)scaled_eps * 1073741824.0);
-        for (int w = 0; w < p.warps; ++w)
+        static const int kRun = 0x7FFFFFFF;
+        SRX_HIP(hipMemcpyAsync(dstop, &kRun, sizeof(int), hipMemcpyHostToDevice, st));
+        if (unfinished >= 0)
         {
-            hipLaunchKernelGGL(k_warp, g2, b2, 0, st, L.I0.as<float>(), L.I1.as<float>(), m.I1x.as<float>(),
-                               m.I1y.as<float>(), L.u1.as<float>(), L.u2.as<float>(), R, C, m.I1wx.as<float>(),
-                               m.I1wy.as<float>(), m.grad.as<float>(), m.rho_c.as<float>());
-            SRX_LAUNCH_CHECK("warp");
-            SRX_HIP(hipMemsetAsync(m.err.get(), 0, (size_t)iters * sizeof(unsigned long long), st));
-            int done = iters; // iterations that ran
-            float* ua[2][2] = {{L.u1.as<float>(), L.u2.as<float>()}, {m.u_alt.as<float>(), m.u_alt.as<float>() + n}};
-            float* pa[2] = {p11, m.p_alt.as<float>()};
-            int& predicted = m.last_done[(size_t)s * p.warps + w];
-            // 0: at most 200 000 pixels, 1: at most 1 000 000, 2: more
-            const int by_size = n > (size_t)1000000 ? 2 : (n > (size_t)200000 ? 1 : 0);
-            const int size_class = p.iterationsPerLaunch == 1 ? 2 : p.iterationsPerLaunch == 4 ? 1
-                                   : p.iterationsPerLaunch == 8 ? 0 : by_size;
-            // Iterations per launch.  Small levels are bound by the time a launch takes whatever it does: 8 iterations
-            // on tiles of 16 x 16.  Levels of a megapixel and more are bound by memory traffic, and the short row
-            // segments of a tile with halo waste too much of every cache line: one iteration per launch on tiles
-            // of 128 x 8 with 16-byte accesses stays the fastest there (40 us per iteration at 1920 x 1080 against
-            // 59 us per iteration for 2 iterations per launch on 32 x 32, 48 us on 128 x 8).
-            const int kt = size_class == 2 ? 1 : (size_class == 1 ? 4 : 8);
-            const int tw = size_class == 0 ? 16 : 32, th = tw;
-            const int n_launch = (iters + kt - 1) / kt;
-            const dim3 gm((C + tw - 1) / tw, (R + th - 1) / th);
-            auto enqueue = [&](int bidx) {
-                const int src = bidx & 1, dst = src ^ 1;
-                Tvl1Planes P;
-                P.I1wx = m.I1wx.as<float>(), P.I1wy = m.I1wy.as<float>(), P.grad = m.grad.as<float>();
-                P.rho_c = m.rho_c.as<float>();
-                P.u1 = ua[src][0], P.u2 = ua[src][1];
-                P.p11 = pa[src], P.p12 = pa[src] + n, P.p21 = pa[src] + 2 * n, P.p22 = pa[src] + 3 * n;
-                P.nu1 = ua[dst][0], P.nu2 = ua[dst][1];
-                P.np11 = pa[dst], P.np12 = pa[dst] + n, P.np21 = pa[dst] + 2 * n, P.np22 = pa[dst] + 3 * n;
-                // (a launch past the last iteration only ever repairs the one before it)
-                const int first = bidx * kt, count = std::max(0, std::min(kt, iters - first));
-                if (size_class == 2) // one iteration per launch: launch `bidx` is iteration `bidx`
-                {
-                    if (C % 4 == 0)
-                        hipLaunchKernelGGL(k_tvl1_iter4, grid2(C, R, dim3(kIt4X, kIt4Y)), dim3(32, kIt4Y + 2), 0, st, P, R, C,
-                                           l_t, theta, taut, m.err.as<unsigned long long>(), bidx, thr);
-                    else
-                        hipLaunchKernelGGL(k_tvl1_iter, grid2(C, R, dim3(kItX, kItY)), dim3(kItX, kItY), 0, st, P, R, C,
-                                           l_t, theta, taut, m.err.as<unsigned long long>(), bidx, thr);
-                }
-                else if (size_class == 1)
-                    hipLaunchKernelGGL((k_tvl1_multi<4, 32, 32, 256>), gm, dim3(256), 0, st, P, R, C, l_t, theta, taut,
-                                       m.err.as<unsigned long long>(), iters, first, count, thr);
-                else
-                    hipLaunchKernelGGL((k_tvl1_multi<8, 16, 16, 1024>), gm, dim3(1024), 0, st, P, R, C, l_t, theta, taut,
-                                       m.err.as<unsigned long long>(), iters, first, count, thr);
-            };
-            // Launches are queued in batches; the error values are looked at after each batch.  The queued
-            // launches stop by themselves on the device (and repair a launch that ran too far); looking here
-            // only saves queueing launches that would return at once.  The batch sizes follow the number of
-            // iterations the same level and warp took for the previous pair.
-            int last_launch = n_launch - 1; // the launch whose output set holds the result
-            for (int b0 = 0, b1 = 0; b0 < n_launch; b0 = b1)
-            {
-                const int batch = b0 == 0 && predicted > 0 ? std::min((predicted + kt - 1) / kt + 1, kPollStride / kt + 1)
-                                                           : std::max(kPollRest / kt, 2);
-                b1 = std::min(b0 + batch, n_launch);
-                for (int bidx = b0; bidx < b1; ++bidx)
-                    enqueue(bidx);
-                SRX_LAUNCH_CHECK("tvl1 iterations");
-                const int it0 = b0 * kt, it1 = std::min(b1 * kt, iters);
-                SRX_HIP(hipMemcpyAsync(herr + it0, m.err.as<unsigned long long>() + it0,
-                                       (size_t)(it1 - it0) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-                SRX_HIP(hipStreamSynchronize(st));
-                bool stop = false;
-                for (int it = it0; it < it1 && !stop; ++it)
-                    if (herr[it] <= thr)
-                    {
-                        done = it + 1;
-                        stop = true;
-                    }
-                if (stop)
-                {
-                    last_launch = (done - 1) / kt;
-                    // a launch that ran past the last iteration is repaired by the launch after it
-                    if (done % kt != 0 && done != iters && last_launch + 1 >= b1)
-                    {
-                        enqueue(last_launch + 1);
-                        SRX_LAUNCH_CHECK("tvl1 iterations (repeat)");
-                    }
-                    break;
-                }
-            }
-            const bool in_second_set = ((last_launch + 1) & 1) != 0;
-            if (in_second_set)
-            {
-                // an odd number of launches leaves the result in the second buffer set
-                SRX_HIP(hipMemcpyAsync(ua[0][0], ua[1][0], n * sizeof(float), hipMemcpyDeviceToDevice, st));
-                SRX_HIP(hipMemcpyAsync(ua[0][1], ua[1][1], n * sizeof(float), hipMemcpyDeviceToDevice, st));
-                SRX_HIP(hipMemcpyAsync(pa[0], pa[1], 4 * n * sizeof(float), hipMemcpyDeviceToDevice, st));
-            }
-            executed += done;
-            m.pixel_iterations += (long long)done * (long long)n;
-            predicted = done;
+            Phase& ph = plan[(size_t)unfinished];
+            const int more = std::min(launch_cap(ph) - ph.n_enq, std::max(ph.n_enq, std::max(kPollRest / ph.kt, 2)));
+            for (int b = ph.n_enq; b < ph.n_enq + more; ++b)
+                launch_iterations(ph, unfinished, b);
+            ph.n_enq += more;
         }
-        if (s > 0)
+        for (int k = resume; k <= n_phases; ++k)
         {
-            Impl::Level& F = m.lv[s - 1];
-            hipLaunchKernelGGL(k_upsample_flow, grid2(F.cols, F.rows, b2), b2, 0, st, L.u1.as<float>(),
-                               L.u2.as<float>(), R, C, F.u1.as<float>(), F.u2.as<float>(), F.rows, F.cols);
-            SRX_LAUNCH_CHECK("upsample_flow");
+            if (k > 0)
+                launch_between(k);
+            if (k == n_phases)
+                break;
+            Phase& ph = plan[(size_t)k];
+            launch_opening(k);
+            ph.n_enq = first_batch(ph, std::max(m.last_done[(size_t)k], m.before_last_done[(size_t)k]));
+            for (int b = 0; b < ph.n_enq; ++b)
+                launch_iterations(ph, k, b);
         }
+        SRX_LAUNCH_CHECK("tvl1 chain");
+        SRX_HIP(hipMemcpyAsync(m.host_err.get(), derr, (err_words + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        SRX_HIP(hipStreamSynchronize(st));
+        const int stop = *hstop;
+        if (stop == kRun)
+            break;
+        if (stop < 1 || stop > n_phases || round > 4 * n_phases + 64)
+        {
+            set_error("tvl1: the launch chain stopped at an impossible phase");
+            return SRX_ERR_DEVICE;
+        }
+        // phase stop - 1 needs more launches; everything from `stop` on (its gate included) is queued again
+        unfinished = stop - 1;
+        resume = stop;
     }
-    hipLaunchKernelGGL(k_merge2, dim3((unsigned)((px0 + 255) / 256)), dim3(256), 0, st, m.lv[0].u1.as<float>(),
-                       m.lv[0].u2.as<float>(), px0, (float2*)flow_uv);
-    SRX_LAUNCH_CHECK("merge2");
+    long long executed = 0;
+    m.pixel_iterations = 0;
+    for (int k = 0; k < n_phases; ++k)
+    {
+        const Phase& ph = plan[(size_t)k];
+        int done = iters;
+        for (int it = 0; it < iters; ++it)
+            if (herr[(size_t)k * iters + it] <= ph.thr)
+            {
+                done = it + 1;
+                break;
+            }
+        executed += done;
+        m.pixel_iterations += (long long)done * (long long)ph.n;
+        m.before_last_done[(size_t)k] = m.last_done[(size_t)k];
+        m.last_done[(size_t)k] = done;
+    }
     if (executed_iters)
         *executed_iters = executed;
     return SRX_OK;

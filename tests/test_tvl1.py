@@ -86,7 +86,7 @@ def test_gpu_flow_matches_oracle_bit_exact(rows, cols, ch, dtype, kw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("per_launch", [1, 4, 8])
+@pytest.mark.parametrize("per_launch", [1, 4, 8, 12, 14])
 @pytest.mark.parametrize("rows,cols,kw", [
     (64, 80, {}),                                             # width a multiple of 4: 16-byte single-iteration kernel
     (33, 47, dict(nscales=3, warps=2, iterations=40)),        # odd width: the one-pixel-per-thread kernel
@@ -94,10 +94,12 @@ def test_gpu_flow_matches_oracle_bit_exact(rows, cols, ch, dtype, kw):
     (41, 132, dict(nscales=2, warps=2, iterations=30)),       # a tile column of 4 pixels behind a full one
 ])
 def test_every_iteration_kernel_matches_the_oracle(rows, cols, kw, per_launch):
-    """The library picks the iteration kernel by the size of the pyramid level: 8 iterations per launch on small
-    levels, 4 on levels up to a megapixel, one above.  Images an oracle run can afford only ever reach the first, so
-    iterationsPerLaunch forces each kernel onto every level: flows and executed iteration counts must be the
-    oracle's with all of them."""
+    """The library picks the iteration kernel by the size and the width of the pyramid level: 8 iterations per
+    launch on small levels, 2 or 4 on regions of whole 512-byte rows above 200 000 pixels where the width is a
+    multiple of 4 (4 on 32 x 32 tiles or one per launch otherwise).  Images an oracle run can afford only ever reach
+    the first, so iterationsPerLaunch forces each kernel onto every level (12 and 14: the whole-row kernel with 2
+    and 4 iterations; levels of other widths fall back to 32 x 32 tiles): flows and executed iteration counts must
+    be the oracle's with all of them."""
     import torch
     from superresolution_amd import api
 
