@@ -515,6 +515,215 @@ __global__ void k_group_flags(const uint32_t* __restrict__ grp, uint8_t* __restr
             all_same ? kRowIdentity : (all_ok ? kRowInside : (n_in < 48 ? kRowOutside : kRowMixed));
 }
 
+// k_build_maps, k_group_maps and k_group_flags in one pass (scale 4): a thread works on one LR cell - the 4 x 4 HR
+// pixels of rows 4y-1 .. 4y+2 and columns 4x .. 4x+3, i.e. the four groups of one 16-byte record of the group map -
+// and a wave on one (LR row, strip) of the forward kernel, lanes as there, so that the row's kind falls out of
+// two ballots at the end.  The bicubic taps of the 16 pixels come from 5 x 5 LR motions (a thread per HR pixel
+// loads 16 for each): the row passes are shared by the pixels of a column, exactly the sums cubic_sample forms,
+// in its order.  Everything leaves as 16-byte stores.  Block row h only finishes HR row H-1 (no group starts
+// there).  The tap tables are cv::resize's (cubic_table_x / _y): per cell the four columns' first taps are
+// (s, s, s + o, s + o) with o = 0 or 1, the four rows' likewise; a lane whose tables say otherwise (no geometry
+// makes them) takes the per-pixel routine.
+__global__ __launch_bounds__(64) void k_build_maps_cells(const float* __restrict__ rel, int h, int w, CubicTables t,
+                                                         short2* __restrict__ fwd_map, short2* __restrict__ bwd_map,
+                                                         uint32_t* __restrict__ dec_fwd, uint32_t* __restrict__ grp,
+                                                         uint8_t* __restrict__ flags, int strips_x)
+{
+    const int H = 4 * h, W = 4 * w;
+    const int strip = blockIdx.x, y = blockIdx.y, lane = threadIdx.x;
+    const int x0 = strip * kFwdStrip;
+    const int x = x0 - 1 + lane;
+    const int xl = min(max(x, 0), w - 1);
+    const bool owner = lane >= 1 && x < w;
+    const bool last = y == h;
+    const int n_rows = last ? 1 : 4;
+    const int N0 = 4 * y - 1;
+    int mrow[4], sy[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+    {
+        mrow[r] = reflect101(min(N0 + r, H - 1), H);
+        sy[r] = t.yofs[mrow[r]];
+    }
+    int base = sy[0];
+#pragma unroll
+    for (int r = 1; r < 4; ++r)
+        base = r < n_rows ? min(base, sy[r]) : base;
+    bool rows_ok = true;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        rows_ok = rows_ok && (r >= n_rows || sy[r] - base <= 1);
+    const int X0 = 4 * xl;
+    int sxv[4];
+    float4 al[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+    {
+        sxv[c] = t.xofs[X0 + c];
+        al[c] = t.alpha[X0 + c];
+    }
+    const int sb = sxv[0];
+    const bool shifted = sxv[2] != sb;
+    const bool shared_taps = rows_ok && sxv[1] == sb && sxv[3] == sxv[2] && (sxv[2] == sb || sxv[2] == sb + 1);
+
+    float mot[4][4][2]; // [HR row][column][x, y]
+    if (shared_taps)
+    {
+        float hv[5][4][2];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+        {
+            const float2* S = (const float2*)rel + (size_t)clampi(base - 1 + i, 0, h - 1) * w;
+            float2 L[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                L[k] = S[clampi(sb - 1 + k, 0, w - 1)];
+#pragma unroll
+            for (int comp = 0; comp < 2; ++comp)
+            {
+                float a[5], b[4];
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    a[k] = comp == 0 ? L[k].x : L[k].y;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    b[k] = shifted ? a[k + 1] : a[k];
+                hv[i][0][comp] = a[0] * al[0].x + a[1] * al[0].y + a[2] * al[0].z + a[3] * al[0].w;
+                hv[i][1][comp] = a[0] * al[1].x + a[1] * al[1].y + a[2] * al[1].z + a[3] * al[1].w;
+                hv[i][2][comp] = b[0] * al[2].x + b[1] * al[2].y + b[2] * al[2].z + b[3] * al[2].w;
+                hv[i][3][comp] = b[0] * al[3].x + b[1] * al[3].y + b[2] * al[3].z + b[3] * al[3].w;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+        {
+            const bool down = sy[r] != base; // the same for the whole block
+            const float4 be = t.beta[mrow[r]];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int comp = 0; comp < 2; ++comp)
+                {
+                    const float v0 = down ? hv[1][c][comp] : hv[0][c][comp], v1 = down ? hv[2][c][comp] : hv[1][c][comp];
+                    const float v2 = down ? hv[3][c][comp] : hv[2][c][comp], v3 = down ? hv[4][c][comp] : hv[3][c][comp];
+                    mot[r][c][comp] = v0 * be.x + v1 * be.y + v2 * be.z + v3 * be.w;
+                }
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+            {
+                float m[2];
+                cubic_sample<2>(rel, h, w, sxv[c], al[c], sy[r], t.beta[mrow[r]], m);
+                mot[r][c][0] = m[0], mot[r][c][1] = m[1];
+            }
+    }
+
+    uint32_t g_short[4], g_long0[4], g_long1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+    {
+        const int N = N0 + r; // the group's own row; its map row is mrow[r] (they differ for N = -1 only)
+        int fx[4], fy[4], bx[4], by[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+        {
+            const float mx = mot[r][c][0] * 4.0f, my = mot[r][c][1] * 4.0f;
+            const float px = (float)(X0 + c), py = (float)mrow[r];
+            fx[c] = round_sat16(px - mx), fy[c] = round_sat16(py - my);
+            bx[c] = round_sat16(px + mx), by[c] = round_sat16(py + my);
+        }
+        if (owner && N >= 0 && r < n_rows)
+        {
+            const size_t o = (size_t)N * W + X0;
+            typedef short __attribute__((ext_vector_type(8))) v8s;
+            *(v8s*)(fwd_map + o) = v8s{(short)fx[0], (short)fy[0], (short)fx[1], (short)fy[1], (short)fx[2], (short)fy[2],
+                                       (short)fx[3], (short)fy[3]};
+            *(v8s*)(bwd_map + o) = v8s{(short)bx[0], (short)by[0], (short)bx[1], (short)by[1], (short)bx[2], (short)by[2],
+                                       (short)bx[3], (short)by[3]};
+            *(uint4*)(dec_fwd + o) = make_uint4(decode_fwd(fx[0], fy[0], H, W), decode_fwd(fx[1], fy[1], H, W),
+                                                decode_fwd(fx[2], fy[2], H, W), decode_fwd(fx[3], fy[3], H, W));
+        }
+        // the group's entries in both forms (k_group_maps)
+        const int col0 = bx[0], row0 = by[0];
+        {
+            const int ddx = clampi(col0 - X0, -63, 63), ddy = clampi(row0 - N, -63, 63);
+            bool far = ddx != col0 - X0 || ddy != row0 - N;
+            uint32_t others = 0;
+#pragma unroll
+            for (int i = 1; i <= 3; ++i)
+            {
+                const int dx = bx[i] - (col0 + i), dy = by[i] - row0;
+                far = far || dx < -4 || dx > 3 || dy < -4 || dy > 3;
+                others |= ((uint32_t)(dx & 7) | ((uint32_t)(dy & 7) << 3)) << (6 * (i - 1));
+            }
+            g_short[r] = far ? kGrpFar : (((uint32_t)ddx & 0x7Fu) | (((uint32_t)ddy & 0x7Fu) << 7) | (others << 14));
+        }
+        {
+            const int ddx = clampi(col0 - X0, -16384, 16383), ddy = clampi(row0 - N, -16384, 16383);
+            bool far = ddx != col0 - X0 || ddy != row0 - N;
+            uint32_t w1 = 0;
+#pragma unroll
+            for (int i = 1; i <= 3; ++i)
+            {
+                const int dx = bx[i] - (col0 + i), dy = by[i] - row0;
+                far = far || dx < -16 || dx > 15 || dy < -16 || dy > 15;
+                w1 |= ((uint32_t)(dx & 31) | ((uint32_t)(dy & 31) << 5)) << (10 * (i - 1));
+            }
+            g_long0[r] = ((uint32_t)ddx & 0x7FFFu) | (((uint32_t)ddy & 0x7FFFu) << 15) | (far ? kGrpLongFar : 0u);
+            g_long1[r] = w1;
+        }
+    }
+    if (last)
+        return;
+    const size_t entries = (size_t)h * w * 4;
+    if (owner)
+    {
+        const size_t cell = (size_t)y * w + xl;
+        ((uint4*)grp)[cell] = make_uint4(g_short[0], g_short[1], g_short[2], g_short[3]);
+        ((uint4*)(grp + entries))[cell] = make_uint4(g_long0[0], g_long0[1], g_long0[2], g_long0[3]);
+        ((uint4*)(grp + 2 * entries))[cell] = make_uint4(g_long1[0], g_long1[1], g_long1[2], g_long1[3]);
+    }
+    // the row's kind (k_group_flags), from the entries just made
+    const int dc_lane = 4 * xl - (4 * (x0 - 1) - kFwdMx);
+    bool ok = true, any = false, same = true;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+    {
+        const uint2 gs = make_uint2(g_short[r], 0u), gl = make_uint2(g_long0[r], g_long1[r]);
+        same = same && gs.x == 0u;
+        bool in_s, in_l;
+        {
+            const int dr = Grp<false>::dr(gs) + kFwdMy + 1 + r, dc = Grp<false>::dc(gs) + dc_lane;
+            in_s = !Grp<false>::far(gs) && (unsigned)dr < (unsigned)kFwdSpan && (unsigned)dc < (unsigned)(4 * kFwdQuads);
+#pragma unroll
+            for (int j = 1; j < 4; ++j)
+                in_s = in_s && (unsigned)(dr + Grp<false>::dy(gs, j)) < (unsigned)kFwdSpan &&
+                       (unsigned)(dc + j + Grp<false>::dx(gs, j)) < (unsigned)(4 * kFwdQuads);
+        }
+        {
+            const int dr = Grp<true>::dr(gl) + kFwdMy + 1 + r, dc = Grp<true>::dc(gl) + dc_lane;
+            in_l = !Grp<true>::far(gl) && (unsigned)dr < (unsigned)kFwdSpan && (unsigned)dc < (unsigned)(4 * kFwdQuads);
+#pragma unroll
+            for (int j = 1; j < 4; ++j)
+                in_l = in_l && (unsigned)(dr + Grp<true>::dy(gl, j)) < (unsigned)kFwdSpan &&
+                       (unsigned)(dc + j + Grp<true>::dx(gl, j)) < (unsigned)(4 * kFwdQuads);
+        }
+        ok = ok && in_s;
+        any = any || in_l;
+    }
+    const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
+    const bool all_same = all_ok && __builtin_amdgcn_ballot_w64(!same) == 0;
+    const int n_in = __builtin_popcountll(__builtin_amdgcn_ballot_w64(any));
+    if (lane == 0)
+        flags[(size_t)y * strips_x + strip] =
+            all_same ? kRowIdentity : (all_ok ? kRowInside : (n_in < 48 ? kRowOutside : kRowMixed));
+}
+
 // ps == 0: interleaved destination; otherwise planar with plane stride ps
 template <int CH>
 __global__ void k_resize_cubic(const float* __restrict__ src, int srows, int scols, CubicTables t,
@@ -2619,6 +2828,16 @@ int launch_build_maps(const float* rel, int rows, int cols, int scale, const Cub
     {
         set_error("build_maps: decoded maps exist for scale 4 (both) and scale 2 (forward) only");
         return 1;
+    }
+    if (scale == 4 && dec_fwd && dec_bwd && g_kernel_path == 0)
+    {
+        // raw maps, decoded forward map, group map and row kinds in one pass
+        const int strips_x = (cols + kFwdStrip - 1) / kFwdStrip;
+        const size_t hr_px = (size_t)rows * 4 * cols * 4;
+        hipLaunchKernelGGL(k_build_maps_cells, dim3(strips_x, rows + 1), dim3(64), 0, st, rel, rows, cols, t,
+                           (short2*)fwd_map, (short2*)bwd_map, dec_fwd, dec_bwd, (uint8_t*)(dec_bwd + 3 * (hr_px / 4)),
+                           strips_x);
+        return check_launch("build_maps_cells");
     }
     const dim3 b(64, 4);
     hipLaunchKernelGGL(k_build_maps, grid2d(cols * scale, rows * scale, b), b, 0, st, rel, rows, cols, scale, t,
