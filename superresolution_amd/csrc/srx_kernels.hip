@@ -1422,14 +1422,15 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
             for (int c = 0; c < CH; ++c)
                 v[j][c] = *(lds_cfloat*)(uintptr_t)(at + c * kFwdRowBytes);
         };
-        auto row_offset = [&](int drj) {
-            int slot = s + drj;
-            slot = (int)min((unsigned)slot, (unsigned)(slot - kFwdRing));
-            return __umul24((unsigned)slot, (unsigned)kSlotBytes);
-        };
+        // Ring rows as byte offsets: row (s + dr0 + d) of the ring starts at d * kSlotBytes + (s + dr0) * kSlotBytes,
+        // less the ring's size when that runs past its end (one multiply-add, a subtraction and a minimum; the
+        // second term is the same for the whole wave).
+        const int ring_base = (s + dr0) * kSlotBytes;
+        auto wrapped = [&](int at) { return min((unsigned)at, (unsigned)(at - kRingBytes)); };
+        const int row0_at = __mul24(G::dr(gm), kSlotBytes) + ring_base; // not wrapped yet: the other rows start from it
         if (!rows_differ)
         {
-            const unsigned row_at = row_offset(dr);
+            const unsigned row_at = wrapped(row0_at);
             pixel(0, row_at, (unsigned)dc);
             unsigned e1 = 0;
 #pragma unroll
@@ -1447,16 +1448,16 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
         }
         else
         {
-            pixel(0, row_offset(dr), (unsigned)dc);
+            pixel(0, wrapped(row0_at), (unsigned)dc);
             unsigned e1 = 0, row1 = 0;
 #pragma unroll
             for (int j = 1; j < 4; ++j)
             {
-                const int drj = dr + G::dy(gm, j);
+                const int dyj = G::dy(gm, j);
                 unsigned e = (unsigned)(dc + j + G::dx(gm, j));
                 if (checked)
-                    far_row = max(far_row, (unsigned)drj), far_col = max(far_col, e);
-                unsigned row_at = row_offset(drj);
+                    far_row = max(far_row, (unsigned)(dr + dyj)), far_col = max(far_col, e);
+                unsigned row_at = wrapped(__mul24(dyj, kSlotBytes) + row0_at);
                 if (j == 1)
                     e1 = e, row1 = row_at;
                 if (j == 3)
