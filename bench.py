@@ -85,6 +85,10 @@ def parse():
                     help="do not bracket the solver kernels with HIP events (the roofline object is then left out)")
     ap.add_argument("--cpu-iters", type=int, default=12, help="iterations of the CPU sample solve")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when this process starts the ranks")
+    ap.add_argument("--pairs-in-flight", type=int, default=3,
+                    help="tvl1 workload: independent frame pairs the library works on side by side (1 .. 4)")
+    ap.add_argument("--pairs-per-step", type=int, default=0,
+                    help="tvl1 workload: pairs of one step = one library call (default: twice --pairs-in-flight)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: every rank solves --steps frames (the default); strong: one clip of --frames outputs "
                          "is cut into one span per rank")
@@ -651,7 +655,8 @@ def bench_strong(args):
 
 
 def bench_tvl1(args):
-    """The flow stage alone: pairs of consecutive grey frames of the synthetic clip, sharded over the ranks."""
+    """The flow stage alone: pairs of consecutive grey frames of the synthetic clip, sharded over the ranks.  A step
+    is one library call on a batch of independent pairs, --pairs-in-flight of them side by side."""
     R = Ranks(args)
     torch = R.torch
     if R.dry:
@@ -661,7 +666,9 @@ def bench_tvl1(args):
     from superresolution_amd import api, spans, synth, _lib as L
 
     rows, cols, dev = args.rows, args.cols, R.dev
-    n_pairs = args.warmup + args.steps
+    in_flight = max(1, args.pairs_in_flight)
+    batch = args.pairs_per_step if args.pairs_per_step > 0 else 2 * in_flight
+    n_pairs = (args.warmup + args.steps) * batch
     # pair t = frames (t, t + 1) of the clip; ranks own disjoint contiguous ranges of pairs
     first, last = spans.pair_shard(R.world * n_pairs, R.world, R.rank)
     assert last - first == n_pairs
@@ -673,26 +680,34 @@ def bench_tvl1(args):
     lib = L.lib()
     import ctypes as C
 
-    def pair(t):
-        _flow, iters = sr.calcFlowDevice(gray[t], gray[t + 1])
-        sr.synchronize()
+    def step(k, lanes=in_flight):
+        t = k * batch
+        _flows, its = sr.calcFlowDevicePairs(gray[t:t + batch], gray[t + 1:t + batch + 1], in_flight=lanes)
         w = C.c_longlong()
         L.check(lib.srx_flow_pixel_iterations(sr.handle, C.byref(w)))
-        return iters, w.value
+        return sum(its) / batch, w.value / batch
 
-    for t in range(args.warmup):
-        pair(t)
+    for k in range(args.warmup):
+        step(k)
     R.sync()
     t0 = time.perf_counter()
     iters, work, step_ms = [], [], []
-    for t in range(args.warmup, n_pairs):
+    for k in range(args.warmup, args.warmup + args.steps):
         ts = time.perf_counter()
-        i, w = pair(t)
+        i, w = step(k)
         step_ms.append((time.perf_counter() - ts) * 1e3)
         iters.append(i)
         work.append(w)
     R.sync()
     elapsed = R.max_over_ranks(time.perf_counter() - t0)
+    # the same pairs one at a time (outside the clock): what a caller with a single pair in hand gets
+    one_ms = None
+    if in_flight > 1:
+        step(args.warmup, lanes=1)
+        ts = time.perf_counter()
+        for k in range(args.warmup, args.warmup + min(args.steps, 3)):
+            step(k, lanes=1)
+        one_ms = (time.perf_counter() - ts) * 1e3 / (min(args.steps, 3) * batch)
     if R.rank == 0:
         bytes_pair = 64.0 * float(np.mean(work))  # 16 floats read or written per pixel and inner iteration
         # HBM-side bytes per pair of all flow kernels from the committed PMC passes (scripts/pmc_tvl1.sh), 1080p only
@@ -706,15 +721,15 @@ def bench_tvl1(args):
                     pair_traffic_src = os.path.relpath(files[-1], ROOT)
             except (OSError, ValueError, KeyError):
                 pass
-        per_pair_s = elapsed / args.steps
+        per_pair_s = elapsed / (args.steps * batch)
         line = {
             "metric": f"TV-L1 flow stage, {cols}x{rows} grey frame pairs per second",
-            "value": R.world * args.steps / elapsed,
+            "value": R.world * args.steps * batch / elapsed,
             "unit": "pairs/s",
             "n_gpus": R.world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": per_pair_s * 1e3,
+            "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -722,8 +737,14 @@ def bench_tvl1(args):
             "data": "synthetic",
             "config": {
                 "workload": f"configs[2]: TV-L1 dual optical flow standalone on {cols}x{rows} grey frame pairs, 5 scales x "
-                            f"5 warps x 300 inner iterations at most (stops per level and warp at epsilon 0.01)",
+                            f"5 warps x 300 inner iterations at most (stops per level and warp at epsilon 0.01); a step "
+                            f"is one call on {batch} independent pair{'s' if batch > 1 else ''}, {in_flight} in flight "
+                            f"side by side",
                 "partition": "frame pairs sharded over the ranks, no exchange",
+                "pairs_per_step": batch,
+                "pairs_in_flight": in_flight,
+                "ms_per_pair": per_pair_s * 1e3,
+                "one_pair_at_a_time_ms_per_pair": None if one_ms is None else round(one_ms, 3),
                 "pairs_per_gpu": {f"rank{g}": list(spans.pair_shard(R.world * n_pairs, R.world, g))
                                   for g in range(R.world)},
                 "executed_inner_iterations_per_pair": float(np.mean(iters)),
@@ -731,13 +752,13 @@ def bench_tvl1(args):
                 "step_ms": [round(v, 2) for v in step_ms],
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_tvl1_iter4 on levels of a megapixel and more (one inner iteration per launch), "
-                                           "k_tvl1_multi below (4 or 8 inner iterations per launch)",
+                "bound": "hbm", "kernel": "k_tvl1_rows on levels of more than 200 000 pixels (2 or 4 inner iterations per "
+                                           "launch), k_tvl1_multi below (8 inner iterations per launch)",
                 "achieved": bytes_pair / per_pair_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": bytes_pair / per_pair_s / 1e9 / HBM_PEAK_GBS, "traffic": pair_traffic,
                 "traffic_source": pair_traffic_src, "algorithmic_bytes_per_pair": bytes_pair,
-                "what": "64 B x executed pixel-iterations over the whole pair time (pyramid, warps, gradient passes "
-                        "and the host's convergence polling included)"},
+                "what": "64 B x executed pixel-iterations over the whole time per pair (pyramid, warps, gradient passes "
+                        "and the host's looks at the convergence words included)"},
         }
         if R.world == 1 and not args.no_cpu_baseline:
             import oracle.tvl1 as ot
@@ -748,8 +769,8 @@ def bench_tvl1(args):
             tc = time.perf_counter()
             ref_flow, n_it = ot.calc_gray(a, b)
             dt = time.perf_counter() - tc
-            got_flow, got_it = sr.calcFlowDevice(gray[0], gray[1])
-            same = bool(np.array_equal(ref_flow, got_flow.cpu().numpy())) and int(got_it) == int(n_it)
+            got_flows, got_its = sr.calcFlowDevicePairs(gray[0:2], gray[1:3], in_flight=min(in_flight, 2))
+            same = bool(np.array_equal(ref_flow, got_flows[0].cpu().numpy())) and int(got_its[0]) == int(n_it)
             if not same:
                 raise RuntimeError("cpu_baseline: the oracle's flow differs from the GPU's for the same pair")
             line["cpu_baseline"] = {

@@ -179,7 +179,18 @@ SRX_API int srx_collect_garbage(srx_handle* h);
  * DenseOpticalFlow::calc, lib/include/optical_flow.hpp:44). */
 SRX_API int srx_flow_calc_device(srx_handle* h, const float* gray0, const float* gray1, int rows, int cols,
                                  float* flow, long long* executed_iterations);
-/* Work of the handle's last built-in TV-L1 call: pixels x executed inner iterations summed over pyramid
+/* The same for n independent pairs (gray0[i] -> gray1[i] into flows[i], all rows x cols, device), up to
+ * in_flight of them side by side (1 .. SRX_MAX_FLOW_PAIRS_IN_FLIGHT), each on a stream and a TV-L1 workspace of
+ * the handle's own: a pyramid's coarse levels are many short launches that leave most of the GPU idle, and
+ * another pair's fill it.  Every flow is the one srx_flow_calc_device returns for its pair.
+ * executed_iterations: n entries or NULL.  Returns when all flows are written.  Farneback pairs run one after the
+ * other.  The reference computes the n - 1 motions of a window one DenseOpticalFlow::calc at a time
+ * (lib/src/btv_l1.cpp:311-316); they are independent pairs like these. */
+#define SRX_MAX_FLOW_PAIRS_IN_FLIGHT 4
+SRX_API int srx_flow_calc_device_pairs(srx_handle* h, int n, const float* const* gray0, const float* const* gray1,
+                                       int rows, int cols, float* const* flows, long long* executed_iterations,
+                                       int in_flight);
+/* Work of the handle's last built-in TV-L1 call (of all pairs of a srx_flow_calc_device_pairs call): pixels x executed inner iterations summed over pyramid
  * levels and warps (each inner iteration moves 64 bytes per pixel of its level; bench.py prices the flow
  * stage with it).  No counterpart in the reference. */
 SRX_API int srx_flow_pixel_iterations(srx_handle* h, long long* pixel_iterations);

@@ -38,5 +38,16 @@ def timed(*fns):
     return best * 1e3
 
 
+def flows_side_by_side(n):
+    def run():
+        flower.calcFlowDevicePairs(gray[:n], gray[1:n + 1], in_flight=n)
+    return run
+
+
 solve(); flow()
+for n in (1, 2, 3, 4):
+    f = flows_side_by_side(n)
+    f()
+    alone, both = timed(f), timed(solve, f)
+    print(f"{n} pairs side by side: alone {alone:.2f} ms ({alone / n:.2f} per pair), beside a solve {both:.2f} ms", flush=True)
 print(f"solve alone {timed(solve):.2f} ms, flow alone {timed(flow):.2f} ms, both at once {timed(solve, flow):.2f} ms", flush=True)

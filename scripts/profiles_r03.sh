@@ -68,7 +68,7 @@ if has tvl1; then
   PAIRS=4
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf $O/pmc_t_$c
-    timeout -s KILL 200 rocprofv3 --pmc $c --output-format csv -d $O/pmc_t_$c -- python3 $R/bench.py --workload tvl1 --steps $PAIRS --warmup 0 --no-cpu-baseline > $O/pmc_t_$c.log 2>&1
+    timeout -s KILL 200 rocprofv3 --pmc $c --output-format csv -d $O/pmc_t_$c -- python3 $R/bench.py --workload tvl1 --pairs-in-flight 1 --pairs-per-step 1 --steps $PAIRS --warmup 0 --no-cpu-baseline > $O/pmc_t_$c.log 2>&1
     echo "pmc tvl1 $c rc=$?"
   done
   python3 $R/scripts/pmc_tvl1.py $O/pmc_t_FETCH_SIZE $O/pmc_t_WRITE_SIZE $PAIRS $O/tvl1_traffic.json

@@ -68,6 +68,8 @@ SIGNATURES = {
     "srx_flow_calc": (C.c_int, [_vp, _imgp, _imgp, _imgp, _imgp]),
     "srx_collect_garbage": (C.c_int, [_vp]),
     "srx_flow_calc_device": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, C.POINTER(C.c_longlong)]),
+    "srx_flow_calc_device_pairs": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, C.POINTER(C.c_longlong),
+                                             C.c_int]),
     "srx_flow_pixel_iterations": (C.c_int, [_vp, C.POINTER(C.c_longlong)]),
     "srx_drain_events": (C.c_int, [_vp, _ip, C.c_int]),
     "srx_ring_slot": (C.c_int, [C.c_int, C.c_int]),

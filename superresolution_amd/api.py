@@ -364,6 +364,30 @@ class BTV_L1:
                                                rows, cols, flow.data_ptr(), C.byref(n)))
         return flow, n.value
 
+    def calcFlowDevicePairs(self, gray0, gray1, in_flight: int = 2):
+        """Built-in flow on n independent pairs of CUDA float grey images (lists of equal-sized tensors), up to
+        `in_flight` pairs side by side; returns (list of (rows, cols, 2) CUDA tensors, list of executed iterations)."""
+        import torch
+
+        n = len(gray0)
+        if len(gray1) != n:
+            raise ValueError("calcFlowDevicePairs: gray0 and gray1 differ in length")
+        if n == 0:
+            return [], []
+        rows, cols = gray0[0].shape
+        a = [g.contiguous() for g in gray0]
+        b = [g.contiguous() for g in gray1]
+        if any(t.shape != (rows, cols) or t.dtype != torch.float32 for t in a + b):
+            raise ValueError("calcFlowDevicePairs: all images must be float32 of one size")
+        flows = [torch.empty((rows, cols, 2), dtype=torch.float32, device=a[0].device) for _ in range(n)]
+        P = C.c_void_p * n
+        its = (C.c_longlong * n)()
+        torch.cuda.synchronize(a[0].device)
+        L.check(self._lib.srx_flow_calc_device_pairs(self._h, n, P(*[t.data_ptr() for t in a]),
+                                                     P(*[t.data_ptr() for t in b]), rows, cols,
+                                                     P(*[t.data_ptr() for t in flows]), its, in_flight))
+        return flows, list(its)
+
     def collectGarbage(self):
         L.check(self._lib.srx_collect_garbage(self._h))
 

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <thread>
 
 using namespace srx;
 
@@ -79,6 +80,15 @@ struct srx_handle
     Tvl1 tvl1;
     FarnebackParams fb_params;
     Farneback farneback;
+    // srx_flow_calc_device_pairs: independent pairs in flight side by side, each on a lane (a stream and a TV-L1
+    // workspace of its own); the first lane is `stream` and `tvl1`
+    struct FlowLane
+    {
+        Tvl1 tvl1;
+        hipStream_t stream = nullptr;
+    };
+    std::vector<std::unique_ptr<FlowLane>> flow_lanes;
+    long long pairs_pixel_iterations = -1; // summed over the pairs of the last ..._pairs call, else -1
     // the built-in flow of this handle on two frames, on the given stream
     int builtin_flow(const srx_image& f0, const srx_image& f1, float* dst, hipStream_t st)
     {
@@ -593,8 +603,16 @@ SRX_API void srx_destroy(srx_handle* h)
     hipEvent_t ev = h->prev_ready, ev2 = h->caller_read;
     if (st2)
         (void)hipStreamSynchronize(st2);
+    std::vector<hipStream_t> lane_streams;
+    for (auto& lane : h->flow_lanes)
+    {
+        (void)hipStreamSynchronize(lane->stream);
+        lane_streams.push_back(lane->stream);
+    }
     const bool dry = h->dry;
     delete h;
+    for (hipStream_t s : lane_streams)
+        (void)hipStreamDestroy(s);
     if (!dry && st)
         (void)hipStreamDestroy(st);
     if (st2)
@@ -1166,7 +1184,105 @@ SRX_API int srx_flow_calc_device(srx_handle* h, const float* gray0, const float*
     }
     else if (int rc = h->tvl1.calc_gray(gray0, gray1, rows, cols, h->flow_params, flow, executed_iterations, h->stream))
         return rc;
+    h->pairs_pixel_iterations = -1;
     SRX_HIP(hipStreamSynchronize(h->stream));
+    return SRX_OK;
+}
+
+SRX_API int srx_flow_calc_device_pairs(srx_handle* h, int n, const float* const* gray0, const float* const* gray1,
+                                       int rows, int cols, float* const* flows, long long* executed_iterations,
+                                       int in_flight)
+{
+    SRX_NEED(h);
+    if (h->dry || n < 0 || (n > 0 && (!gray0 || !gray1 || !flows)))
+    {
+        set_error("srx_flow_calc_device_pairs: needs a GPU handle, n >= 0 and non-NULL lists");
+        return SRX_ERR_INVALID;
+    }
+    if (in_flight < 1 || in_flight > SRX_MAX_FLOW_PAIRS_IN_FLIGHT)
+    {
+        set_error("srx_flow_calc_device_pairs: in_flight must be 1 .. " + std::to_string(SRX_MAX_FLOW_PAIRS_IN_FLIGHT));
+        return SRX_ERR_INVALID;
+    }
+    for (int i = 0; i < n; ++i)
+        if (!gray0[i] || !gray1[i] || !flows[i])
+        {
+            set_error("srx_flow_calc_device_pairs: pair " + std::to_string(i) + " has a NULL image");
+            return SRX_ERR_INVALID;
+        }
+    if (int rc = h->set_device())
+        return rc;
+    if (h->flow_kind == SRX_FLOW_FARNEBACK) // one workspace: pair after pair
+    {
+        for (int i = 0; i < n; ++i)
+        {
+            if (int rc = h->farneback.calc_gray(gray0[i], gray1[i], rows, cols, h->fb_params, flows[i], h->stream))
+                return rc;
+            if (executed_iterations)
+                executed_iterations[i] = 0;
+        }
+        h->pairs_pixel_iterations = 0;
+        SRX_HIP(hipStreamSynchronize(h->stream));
+        return SRX_OK;
+    }
+    const int lanes = std::max(1, std::min(in_flight, n));
+    while ((int)h->flow_lanes.size() < lanes - 1)
+    {
+        std::unique_ptr<srx_handle::FlowLane> lane(new srx_handle::FlowLane);
+        SRX_HIP(hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking));
+        h->flow_lanes.push_back(std::move(lane));
+    }
+    // One host thread per lane: a pair's launches are queued in portions with a look at the device's verdict in
+    // between, and the lanes must not wait for each other's looks.
+    std::vector<int> rcs((size_t)lanes, SRX_OK);
+    std::vector<std::string> errors((size_t)lanes);
+    std::vector<long long> work((size_t)lanes, 0);
+    auto run_lane = [&](int lane) {
+        Tvl1& flow = lane == 0 ? h->tvl1 : h->flow_lanes[(size_t)lane - 1]->tvl1;
+        const hipStream_t st = lane == 0 ? h->stream : h->flow_lanes[(size_t)lane - 1]->stream;
+        int rc = SRX_OK;
+        if (lane > 0 && hipSetDevice(h->device) != hipSuccess)
+        {
+            set_error("srx_flow_calc_device_pairs: hipSetDevice failed in a lane's thread");
+            rc = SRX_ERR_DEVICE;
+        }
+        for (int i = lane; i < n && rc == SRX_OK; i += lanes)
+        {
+            long long iters = 0;
+            rc = flow.calc_gray(gray0[i], gray1[i], rows, cols, h->flow_params, flows[i], &iters, st);
+            if (rc == SRX_OK)
+            {
+                work[(size_t)lane] += flow.pixel_iterations();
+                if (executed_iterations)
+                    executed_iterations[i] = iters;
+            }
+        }
+        if (hipStreamSynchronize(st) != hipSuccess && rc == SRX_OK)
+        {
+            set_error("srx_flow_calc_device_pairs: stream synchronisation failed");
+            rc = SRX_ERR_DEVICE;
+        }
+        rcs[(size_t)lane] = rc;
+        if (rc != SRX_OK)
+            errors[(size_t)lane] = last_error(); // the message is the thread's own
+    };
+    std::vector<std::thread> threads;
+    for (int lane = 1; lane < lanes; ++lane)
+        threads.emplace_back(run_lane, lane);
+    if (n > 0)
+        run_lane(0);
+    for (std::thread& t : threads)
+        t.join();
+    h->pairs_pixel_iterations = 0;
+    for (int lane = 0; lane < lanes; ++lane)
+    {
+        if (rcs[(size_t)lane] != SRX_OK)
+        {
+            set_error(errors[(size_t)lane]);
+            return rcs[(size_t)lane];
+        }
+        h->pairs_pixel_iterations += work[(size_t)lane];
+    }
     return SRX_OK;
 }
 
@@ -1178,7 +1294,7 @@ SRX_API int srx_flow_pixel_iterations(srx_handle* h, long long* pixel_iterations
         set_error("srx_flow_pixel_iterations: NULL argument");
         return SRX_ERR_INVALID;
     }
-    *pixel_iterations = h->tvl1.pixel_iterations();
+    *pixel_iterations = h->pairs_pixel_iterations >= 0 ? h->pairs_pixel_iterations : h->tvl1.pixel_iterations();
     return SRX_OK;
 }
 
@@ -1191,6 +1307,8 @@ SRX_API int srx_collect_garbage(srx_handle* h)
         return rc;
     SRX_HIP(hipStreamSynchronize(h->stream));
     h->tvl1.release();
+    for (auto& lane : h->flow_lanes)
+        lane->tvl1.release();
     h->farneback.release();
     h->staging.release();
     h->flow_dev.release();
