@@ -113,7 +113,9 @@ SRX_API const char* srx_last_error(void);
  * outputMemory (SRX_MEM_*; default host), traceEvents (0/1), kernelTiming (0/1),
  * readAhead (0/1, default 0; built-in flow only): srx_next_frame pulls the frame of the NEXT call from the
  * source while the current solve runs and computes its flow on a second stream.  Same frames out; the
- * source is read one frame earlier than BTV_L1::processImpl (lib/src/btv_l1.cpp:490-509) would. */
+ * source is read one frame earlier than BTV_L1::processImpl (lib/src/btv_l1.cpp:490-509) would;
+ * flowPairsInFlight (1 .. SRX_MAX_FLOW_PAIRS_IN_FLIGHT, default 3; built-in TV-L1 only): how many of the flows
+ * frame i -> base that srx_process computes for a window (lib/src/btv_l1.cpp:311-321) run side by side. */
 SRX_API int srx_set_int(srx_handle* h, const char* name, int value);
 SRX_API int srx_set_double(srx_handle* h, const char* name, double value);
 SRX_API int srx_get_int(srx_handle* h, const char* name, int* value);
@@ -126,7 +128,7 @@ SRX_API int srx_set_flow_callback(srx_handle* h, srx_flow_fn fn, void* user);
 SRX_API int srx_set_flow_callback2(srx_handle* h, srx_flow2_fn fn, void* user);
 /* parameters of the built-in flows.  TV-L1: tau, lambda, theta, epsilon (double); nscales, warps,
  * iterations (int); iterationsPerLaunch (int: 0 = chosen by the size of the pyramid level, the default;
- * 1, 4 or 8 = that kernel at every level - the flows and iteration counts are the same).  Farneback (names of lib/include/optical_flow.hpp's class Farneback): pyrScale,
+ * 1, 4, 8, 12 or 14 = one kernel at every level - the flows and iteration counts are the same).  Farneback (names of lib/include/optical_flow.hpp's class Farneback): pyrScale,
  * polySigma (double); numLevels, winSize, numIters, polyN, flags (int; 0 = box window, 256 = Gaussian
  * window as OPTFLOW_FARNEBACK_GAUSSIAN; an initial flow, flag 4, is not built). */
 SRX_API int srx_flow_set_int(srx_handle* h, const char* name, int value);

@@ -573,6 +573,7 @@ class BTV_L1 : public SuperResolution, private BTV_L1_Base
     void setOutputRange(int first, int last) { check(srx_set_output_range(h_, first, last)); }
     void setOutputOnDevice(bool on) { set("outputMemory", on ? SRX_MEM_DEVICE : SRX_MEM_HOST); }
     void setReadAhead(bool on) { set("readAhead", on ? 1 : 0); } // next frame's flow beside the current solve
+    void setFlowPairsInFlight(int n) { set("flowPairsInFlight", n); } // process(): a window's TV-L1 flows side by side
 
     // DenseOpticalFlow::calc through this object's flow (lib/include/optical_flow.hpp:44)
     void calcFlow(const Mat& frame0, const Mat& frame1, Mat& flow1, Mat* flow2 = nullptr)

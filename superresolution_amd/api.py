@@ -19,7 +19,7 @@ import numpy as np
 from . import _lib as L
 
 _INT_PARAMS = ("scale", "iterations", "btvKernelSize", "blurKernelSize", "temporalAreaRadius", "outputMemory",
-               "traceEvents", "kernelTiming", "readAhead")
+               "traceEvents", "kernelTiming", "readAhead", "flowPairsInFlight")
 _DOUBLE_PARAMS = ("tau", "lambda", "alpha", "blurSigma")
 
 

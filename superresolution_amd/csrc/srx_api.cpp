@@ -122,6 +122,7 @@ struct srx_handle
     // readAhead: the frame of the NEXT call is read, and its flow computed on a second stream,
     // while the solve of this call runs.  Same results, one frame more read from the source.
     int readAhead = 0;
+    int flowPairsInFlight = 3; // srx_process without motions: built-in TV-L1 flows of a window side by side
     hipStream_t stream2 = nullptr;
     hipEvent_t prev_ready = nullptr;
     bool look_valid = false, look_end = false;
@@ -555,6 +556,58 @@ int srx_handle::process_impl(srx_image* out, bool* produced)
 }
 
 // ===========================================================================
+// Independent TV-L1 jobs 0 .. n-1 on up to `in_flight` lanes side by side: job i runs as fn(flow, stream, i) on lane
+// i % lanes, the first lane being the handle's own stream and workspace, every further lane on a host thread of its
+// own (a job's launches are queued in portions with a look at the device's verdict in between, and the lanes must
+// not wait for each other's looks).  Returns when every lane's stream is idle; the first failing lane's code and
+// message are the call's.
+template <typename Fn> static int run_flow_lanes(srx_handle* h, int n, int in_flight, Fn fn)
+{
+    const int lanes = std::max(1, std::min(std::min(in_flight, SRX_MAX_FLOW_PAIRS_IN_FLIGHT), n));
+    while ((int)h->flow_lanes.size() < lanes - 1)
+    {
+        std::unique_ptr<srx_handle::FlowLane> lane(new srx_handle::FlowLane);
+        SRX_HIP(hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking));
+        h->flow_lanes.push_back(std::move(lane));
+    }
+    std::vector<int> rcs((size_t)lanes, SRX_OK);
+    std::vector<std::string> errors((size_t)lanes);
+    auto run_lane = [&](int lane) {
+        Tvl1& flow = lane == 0 ? h->tvl1 : h->flow_lanes[(size_t)lane - 1]->tvl1;
+        const hipStream_t st = lane == 0 ? h->stream : h->flow_lanes[(size_t)lane - 1]->stream;
+        int rc = SRX_OK;
+        if (lane > 0 && hipSetDevice(h->device) != hipSuccess)
+        {
+            set_error("flow lanes: hipSetDevice failed in a lane's thread");
+            rc = SRX_ERR_DEVICE;
+        }
+        for (int i = lane; i < n && rc == SRX_OK; i += lanes)
+            rc = fn(flow, st, i);
+        if (hipStreamSynchronize(st) != hipSuccess && rc == SRX_OK)
+        {
+            set_error("flow lanes: stream synchronisation failed");
+            rc = SRX_ERR_DEVICE;
+        }
+        rcs[(size_t)lane] = rc;
+        if (rc != SRX_OK)
+            errors[(size_t)lane] = last_error(); // the message is the thread's own
+    };
+    std::vector<std::thread> threads;
+    for (int lane = 1; lane < lanes; ++lane)
+        threads.emplace_back(run_lane, lane);
+    if (n > 0)
+        run_lane(0);
+    for (std::thread& t : threads)
+        t.join();
+    for (int lane = 0; lane < lanes; ++lane)
+        if (rcs[(size_t)lane] != SRX_OK)
+        {
+            set_error(errors[(size_t)lane]);
+            return rcs[(size_t)lane];
+        }
+    return SRX_OK;
+}
+
 extern "C"
 {
 
@@ -647,6 +700,8 @@ static int* int_param(srx_handle* h, const std::string& n)
         return &h->outputMemory;
     if (n == "readAhead")
         return &h->readAhead;
+    if (n == "flowPairsInFlight")
+        return &h->flowPairsInFlight;
     return nullptr;
 }
 static double* double_param(srx_handle* h, const std::string& n)
@@ -695,6 +750,16 @@ SRX_API int srx_set_int(srx_handle* h, const char* name, int value)
         if (n == "readAhead")
         {
             *p = value != 0;
+            return SRX_OK;
+        }
+        if (n == "flowPairsInFlight")
+        {
+            if (value < 1 || value > SRX_MAX_FLOW_PAIRS_IN_FLIGHT)
+            {
+                *p = keep;
+                set_error("flowPairsInFlight must be 1 .. " + std::to_string(SRX_MAX_FLOW_PAIRS_IN_FLIGHT));
+                return SRX_ERR_INVALID;
+            }
             return SRX_OK;
         }
         if (int rc = validate_params(h->p))
@@ -1057,7 +1122,9 @@ static int process_batch_impl(srx_handle* h, const srx_image* frames, int n, con
     }
     else
     {
-        // flow frame i -> base for every i != base, zero for the base (lib/src/btv_l1.cpp:311-321)
+        // flow frame i -> base for every i != base, zero for the base (lib/src/btv_l1.cpp:311-321); the built-in
+        // TV-L1 computes these independent pairs side by side (flowPairsInFlight of them)
+        const bool side_by_side = !dry && h->flow_kind == SRX_FLOW_TVL1 && h->flowPairsInFlight > 1 && n > 2;
         for (int i = 0; i < n; ++i)
         {
             if (dry)
@@ -1070,12 +1137,25 @@ static int process_batch_impl(srx_handle* h, const srx_image* frames, int n, con
                 return rc;
             if (i == base_idx)
                 SRX_HIP(hipMemsetAsync(h->batch_motions[i].get(), 0, px * 2 * sizeof(float), h->stream));
-            else if ((rc = h->calc_flow(frames[i], frames[base_idx], h->batch_motions[i].as<float>())))
+            else if (!side_by_side && (rc = h->calc_flow(frames[i], frames[base_idx], h->batch_motions[i].as<float>())))
                 return rc;
             m[i] = h->batch_motions[i].as<float>();
         }
         if (dry)
             return SRX_OK;
+        if (side_by_side)
+        {
+            int others[kMaxWindow], n_others = 0;
+            for (int i = 0; i < n; ++i)
+                if (i != base_idx)
+                    others[n_others++] = i;
+            rc = run_flow_lanes(h, n_others, h->flowPairsInFlight, [&](Tvl1& flow, hipStream_t st, int j) {
+                const int i = others[j];
+                return flow.calc_images(frames[i], frames[base_idx], h->flow_params, h->batch_motions[i].as<float>(), nullptr, st);
+            });
+            if (rc)
+                return rc;
+        }
         if (f0.depth == SRX_8U)
             h->solver.byte_frames(y8, n);
         rc = h->solver.run(y, m, n, base_idx, rows, cols, ch, h->p, nullptr, nullptr, h->stream);
@@ -1225,64 +1305,21 @@ SRX_API int srx_flow_calc_device_pairs(srx_handle* h, int n, const float* const*
         SRX_HIP(hipStreamSynchronize(h->stream));
         return SRX_OK;
     }
-    const int lanes = std::max(1, std::min(in_flight, n));
-    while ((int)h->flow_lanes.size() < lanes - 1)
-    {
-        std::unique_ptr<srx_handle::FlowLane> lane(new srx_handle::FlowLane);
-        SRX_HIP(hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking));
-        h->flow_lanes.push_back(std::move(lane));
-    }
-    // One host thread per lane: a pair's launches are queued in portions with a look at the device's verdict in
-    // between, and the lanes must not wait for each other's looks.
-    std::vector<int> rcs((size_t)lanes, SRX_OK);
-    std::vector<std::string> errors((size_t)lanes);
-    std::vector<long long> work((size_t)lanes, 0);
-    auto run_lane = [&](int lane) {
-        Tvl1& flow = lane == 0 ? h->tvl1 : h->flow_lanes[(size_t)lane - 1]->tvl1;
-        const hipStream_t st = lane == 0 ? h->stream : h->flow_lanes[(size_t)lane - 1]->stream;
-        int rc = SRX_OK;
-        if (lane > 0 && hipSetDevice(h->device) != hipSuccess)
-        {
-            set_error("srx_flow_calc_device_pairs: hipSetDevice failed in a lane's thread");
-            rc = SRX_ERR_DEVICE;
-        }
-        for (int i = lane; i < n && rc == SRX_OK; i += lanes)
-        {
-            long long iters = 0;
-            rc = flow.calc_gray(gray0[i], gray1[i], rows, cols, h->flow_params, flows[i], &iters, st);
-            if (rc == SRX_OK)
-            {
-                work[(size_t)lane] += flow.pixel_iterations();
-                if (executed_iterations)
-                    executed_iterations[i] = iters;
-            }
-        }
-        if (hipStreamSynchronize(st) != hipSuccess && rc == SRX_OK)
-        {
-            set_error("srx_flow_calc_device_pairs: stream synchronisation failed");
-            rc = SRX_ERR_DEVICE;
-        }
-        rcs[(size_t)lane] = rc;
-        if (rc != SRX_OK)
-            errors[(size_t)lane] = last_error(); // the message is the thread's own
-    };
-    std::vector<std::thread> threads;
-    for (int lane = 1; lane < lanes; ++lane)
-        threads.emplace_back(run_lane, lane);
-    if (n > 0)
-        run_lane(0);
-    for (std::thread& t : threads)
-        t.join();
+    std::vector<long long> work((size_t)std::max(n, 1), 0);
+    const int rc = run_flow_lanes(h, n, in_flight, [&](Tvl1& flow, hipStream_t st, int i) {
+        long long iters = 0;
+        if (int rc = flow.calc_gray(gray0[i], gray1[i], rows, cols, h->flow_params, flows[i], &iters, st))
+            return rc;
+        work[(size_t)i] = flow.pixel_iterations();
+        if (executed_iterations)
+            executed_iterations[i] = iters;
+        return (int)SRX_OK;
+    });
+    if (rc)
+        return rc;
     h->pairs_pixel_iterations = 0;
-    for (int lane = 0; lane < lanes; ++lane)
-    {
-        if (rcs[(size_t)lane] != SRX_OK)
-        {
-            set_error(errors[(size_t)lane]);
-            return rcs[(size_t)lane];
-        }
-        h->pairs_pixel_iterations += work[(size_t)lane];
-    }
+    for (int i = 0; i < n; ++i)
+        h->pairs_pixel_iterations += work[(size_t)i];
     return SRX_OK;
 }
 

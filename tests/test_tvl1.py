@@ -179,6 +179,39 @@ def test_pairs_side_by_side_are_the_flows_of_the_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mem", ["host", "device"])
+def test_batch_process_computes_the_windows_flows_side_by_side(mem):
+    """process(frames, None, base) with the built-in TV-L1: the flows frame i -> base (lib/src/btv_l1.cpp:311-321)
+    are independent pairs and run flowPairsInFlight at a time; the result is the oracle's for the oracle's flows,
+    whatever that number."""
+    import torch
+    import oracle
+    from superresolution_amd import api, _lib as L
+
+    lr, _, _ = synth.make_sequence(5, 40, 56, 3, 4, seed=23)
+    frames = [f.numpy() for f in lr]
+    base = 2
+    rel = [np.zeros((40, 56, 2), np.float32) if i == base else
+           tvl1.calc_gray(tvl1.to_gray(frames[i]), tvl1.to_gray(frames[base]))[0] for i in range(5)]
+    p = oracle.BtvParams(iterations=4)
+    want = oracle.btvl1_run([f.astype(np.float32) for f in frames], rel, base, p)
+    want8 = oracle.convert_8u(want)
+    sr = api.BTV_L1()
+    sr.set("iterations", 4)
+    sr.setOpticalFlow(api.DualTVL1())
+    src = frames if mem == "host" else [torch.from_numpy(f).cuda() for f in frames]
+    assert sr.getInt("flowPairsInFlight") == 3
+    for k in (3, 1, 4):
+        sr.set("flowPairsInFlight", k)
+        got = sr.process(src, None, base)
+        got = got.cpu().numpy() if hasattr(got, "cpu") else got
+        assert np.array_equal(got, want8), k
+    with pytest.raises(L.SrxError, match="flowPairsInFlight"):
+        sr.set("flowPairsInFlight", 5)
+    assert sr.getInt("flowPairsInFlight") == 4
+
+
+@pytest.mark.gpu
 def test_streaming_with_builtin_flow_matches_oracle():
     """End to end: TV-L1 flow feeding the BTV-L1 solver, against the oracle driver with the oracle flow."""
     import oracle
