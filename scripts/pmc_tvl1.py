@@ -12,7 +12,7 @@ import json
 import sys
 
 KERNELS = ("k_tvl1", "k_warp", "k_pyr_down", "k_centered_gradient", "k_to_gray", "k_upsample_flow", "k_copy16", "k_settle",
-           "k_phase_gate", "k_zero_guarded", "k_merge2")
+           "k_phase_gate", "k_zero_guarded", "k_merge2", "k_boundary", "k_open_level")
 
 
 def totals(d, counter):

@@ -204,8 +204,12 @@ __global__ void k_to_gray(const void* __restrict__ src, size_t count, int ch, in
 }
 
 // 5-tap binomial {1,4,6,4,1}, REFLECT_101, even samples
-__global__ void k_pyr_down(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst, int dr, int dc)
+__global__ void k_pyr_down(const float* __restrict__ src0, const float* __restrict__ src1, int rows, int cols,
+                           float* __restrict__ dst0, float* __restrict__ dst1, int dr, int dc)
 {
+    // both images of the pair in one launch: blockIdx.z picks the image
+    const float* __restrict__ src = blockIdx.z ? src1 : src0;
+    float* __restrict__ dst = blockIdx.z ? dst1 : dst0;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= dc || y >= dr)
@@ -224,7 +228,7 @@ __global__ void k_pyr_down(const float* __restrict__ src, int rows, int cols, fl
 
 // All launches of a frame pair are queued without the host looking at anything in between.  The pair is a chain
 // of phases, one per (level, warp); *stop is the first phase that must not run yet because the phase before it
-// has not finished within the launches queued for it (k_phase_gate).  Every kernel of phase `phase` and later
+// has not finished within the launches queued for it (k_boundary).  Every kernel of phase `phase` and later
 // then returns at once, which leaves the unfinished phase's state untouched for the host to continue from.
 struct Guard
 {
@@ -236,22 +240,6 @@ __device__ __forceinline__ bool stopped(const Guard g)
     return g.stop != nullptr && *g.stop <= g.phase;
 }
 
-__global__ void k_centered_gradient(const float* __restrict__ src, int rows, int cols, float* __restrict__ dx,
-                                    float* __restrict__ dy, Guard guard)
-{
-    if (stopped(guard))
-        return;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= cols || y >= rows)
-        return;
-    const int xm = x > 0 ? x - 1 : 0, xp = x < cols - 1 ? x + 1 : cols - 1;
-    const int ym = y > 0 ? y - 1 : 0, yp = y < rows - 1 ? y + 1 : rows - 1;
-    const size_t i = (size_t)y * cols + x;
-    dx[i] = 0.5f * (src[(size_t)y * cols + xp] - src[(size_t)y * cols + xm]);
-    dy[i] = 0.5f * (src[(size_t)yp * cols + x] - src[(size_t)ym * cols + x]);
-}
-
 __device__ __forceinline__ void cubic_coeffs(float x, float (&c)[4])
 {
     const float A = -0.75f;
@@ -261,21 +249,14 @@ __device__ __forceinline__ void cubic_coeffs(float x, float (&c)[4])
     c[3] = 1.f - c[0] - c[1] - c[2];
 }
 
-// bicubic warp of I1, I1x, I1y by (u1, u2), zero outside; grad = |grad I1w|^2,
+// bicubic warp of I1, I1x, I1y by (u1, u2) = (a, b) at pixel (x, y), zero outside; grad = |grad I1w|^2,
 // rho_c = I1w - I1wx*u1 - I1wy*u2 - I0
-__global__ void k_warp(const float* __restrict__ I0, const float* __restrict__ I1, const float* __restrict__ I1x,
-                       const float* __restrict__ I1y, const float* __restrict__ u1, const float* __restrict__ u2,
-                       int rows, int cols, float* __restrict__ I1wx, float* __restrict__ I1wy,
-                       float* __restrict__ grad, float* __restrict__ rho_c, Guard guard)
+__device__ __forceinline__ void warp_at(const float* __restrict__ I0, const float* __restrict__ I1,
+                                        const float* __restrict__ I1x, const float* __restrict__ I1y, float a, float b,
+                                        int x, int y, int rows, int cols, float* __restrict__ I1wx,
+                                        float* __restrict__ I1wy, float* __restrict__ grad, float* __restrict__ rho_c)
 {
-    if (stopped(guard))
-        return;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= cols || y >= rows)
-        return;
     const size_t i = (size_t)y * cols + x;
-    const float a = u1[i], b = u2[i];
     const float fx = (float)x + a, fy = (float)y + b;
     float w = 0.f, wx = 0.f, wy = 0.f;
     if (fabsf(fx) < 1e8f && fabsf(fy) < 1e8f)
@@ -313,6 +294,21 @@ __global__ void k_warp(const float* __restrict__ I0, const float* __restrict__ I
     I1wy[i] = wy;
     grad[i] = wx * wx + wy * wy;
     rho_c[i] = w - wx * a - wy * b - I0[i];
+}
+
+__global__ void k_warp(const float* __restrict__ I0, const float* __restrict__ I1, const float* __restrict__ I1x,
+                       const float* __restrict__ I1y, const float* __restrict__ u1, const float* __restrict__ u2,
+                       int rows, int cols, float* __restrict__ I1wx, float* __restrict__ I1wy,
+                       float* __restrict__ grad, float* __restrict__ rho_c, Guard guard)
+{
+    if (stopped(guard))
+        return;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= cols || y >= rows)
+        return;
+    const size_t i = (size_t)y * cols + x;
+    warp_at(I0, I1, I1x, I1y, u1[i], u2[i], x, y, rows, cols, I1wx, I1wy, grad, rho_c);
 }
 
 __device__ __forceinline__ unsigned long long error_term(float du1, float du2)
@@ -1023,16 +1019,11 @@ __global__ __launch_bounds__(NT, 4) void k_tvl1_rows(Tvl1Planes P, int rows, int
     }
 }
 
-// cv::resize(INTER_LINEAR) of the two flow planes to the next finer level, times 2
-__global__ void k_upsample_flow(const float* __restrict__ s1, const float* __restrict__ s2, int srows, int scols,
-                                float* __restrict__ d1, float* __restrict__ d2, int drows, int dcols, Guard guard)
+// cv::resize(INTER_LINEAR) of the two flow planes to the next finer level, times 2: destination pixel (dx, dy)
+__device__ __forceinline__ void upsample_at(const float* __restrict__ s1, const float* __restrict__ s2, int srows,
+                                            int scols, float* __restrict__ d1, float* __restrict__ d2, int drows,
+                                            int dcols, int dx, int dy)
 {
-    if (stopped(guard))
-        return;
-    const int dx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int dy = blockIdx.y * blockDim.y + threadIdx.y;
-    if (dx >= dcols || dy >= drows)
-        return;
     const double scx = 1.0 / ((double)dcols / scols), scy = 1.0 / ((double)drows / srows);
     float fx = (float)((dx + 0.5) * scx - 0.5);
     int sx = (int)floor((double)fx);
@@ -1083,76 +1074,116 @@ __device__ __forceinline__ int first_converged(const unsigned long long* __restr
     return first;
 }
 
-// Has the phase before `phase` finished within the n_enq launches of kt iterations queued for it?  It has when
-// an iteration met the threshold and the launch that holds it either ended with it or is followed by another
-// queued launch (which repairs the overrun), or when all `iters` iterations were queued and none met it.
-// Otherwise *stop becomes `phase` (unless an earlier phase already stopped the chain).  One wave.
-__global__ void k_phase_gate(const unsigned long long* __restrict__ err_prev, int n_enq, int kt, int iters,
-                             unsigned long long thr, int* __restrict__ stop, int phase)
+// What stands between two phases in one launch, one thread per pixel of the finished phase's level.
+//   The gate: has the phase before `phase` finished within the n_enq launches of kt iterations queued for it?  It
+//   has when an iteration met the threshold and the launch that holds it either ended with it or is followed by
+//   another queued launch (which repairs the overrun), or when all `iters` iterations were queued and none met
+//   it.  Otherwise *stop becomes `phase` (unless an earlier phase already stopped the chain) and nothing else
+//   happens.  Every block evaluates the rule alike; block 0 records the stop.
+//   The settling: a finished phase leaves its result in the buffer set its last launch wrote, set
+//   (last_launch + 1) & 1.  The next phase reads set 0, so a result in set 1 is copied over (a pixel's two flow
+//   values and four dual values).
+//   By MODE, 1: the warp that opens the next phase of the same level (it reads the flow of its own pixel only,
+//   so it can follow the settling without a grid-wide wait); 2: the pair's result, the interleaved flow.
+// MODE 0 is gate and settling alone (the next phase is on another level).
+struct Boundary
 {
-    if (*stop <= phase)
-        return;
-    const int queued = min(n_enq * kt, iters);
-    const int first = first_converged(err_prev, queued, thr, (int)threadIdx.x);
-    bool complete;
-    if (first == 0x7FFFFFFF)
-        complete = queued >= iters;
-    else
-        complete = first % kt == kt - 1 || first == iters - 1 || first / kt + 1 < n_enq;
-    if (!complete && threadIdx.x == 0)
-        *stop = phase;
-}
-
-// A finished phase leaves its result in the buffer set its last launch wrote: set (last_launch + 1) & 1.  The next
-// phase reads set 0, so a result in set 1 is copied over (u: 2 planes of n, p: 4 planes of n, contiguous).
-__global__ __launch_bounds__(256) void k_settle(const unsigned long long* __restrict__ err, int kt, int iters,
-                                                 unsigned long long thr, float* __restrict__ u1, float* __restrict__ u2,
-                                                 const float* __restrict__ u_alt, float* __restrict__ p,
-                                                 const float* __restrict__ p_alt, size_t n, Guard guard)
+    const unsigned long long* err_prev;
+    int n_enq, kt, iters;
+    unsigned long long thr;
+    int* stop;
+    int phase;
+    float *u1, *u2;
+    const float* u_alt;
+    float* p;
+    const float* p_alt;
+    int rows, cols;
+};
+struct WarpPlanes
 {
-    if (stopped(guard))
+    const float *I0, *I1, *I1x, *I1y;
+    float *I1wx, *I1wy, *grad, *rho_c;
+};
+template <int MODE>
+__global__ __launch_bounds__(256) void k_boundary(Boundary B, WarpPlanes W, float2* __restrict__ flow_uv)
+{
+    if (*B.stop <= B.phase)
         return;
     __shared__ int s_first;
-    if (threadIdx.x < 64)
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    const int queued = min(B.n_enq * B.kt, B.iters);
+    if (tid < 64)
     {
-        const int f = first_converged(err, iters, thr, (int)threadIdx.x);
-        if (threadIdx.x == 0)
+        const int f = first_converged(B.err_prev, queued, B.thr, tid);
+        if (tid == 0)
             s_first = f;
     }
     __syncthreads();
-    const int done = s_first == 0x7FFFFFFF ? iters : s_first + 1;
-    const int last_launch = (done - 1) / kt;
-    if (((last_launch + 1) & 1) == 0)
-        return;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 6 * n; i += stride)
+    const int first = s_first;
+    bool complete;
+    if (first == 0x7FFFFFFF)
+        complete = queued >= B.iters;
+    else
+        complete = first % B.kt == B.kt - 1 || first == B.iters - 1 || first / B.kt + 1 < B.n_enq;
+    if (!complete)
     {
-        if (i < n)
-            u1[i] = u_alt[i];
-        else if (i < 2 * n)
-            u2[i - n] = u_alt[i];
-        else
-            p[i - 2 * n] = p_alt[i - 2 * n];
+        if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0)
+            *B.stop = B.phase;
+        return;
     }
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= B.cols || y >= B.rows)
+        return;
+    const size_t n = (size_t)B.rows * B.cols, i = (size_t)y * B.cols + x;
+    const int done = first == 0x7FFFFFFF ? B.iters : first + 1;
+    const bool in_alt = (((done - 1) / B.kt + 1) & 1) != 0;
+    float a, b;
+    if (in_alt)
+    {
+        a = B.u_alt[i], b = B.u_alt[n + i];
+        B.u1[i] = a, B.u2[i] = b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            B.p[j * n + i] = B.p_alt[j * n + i];
+    }
+    else if (MODE != 0)
+        a = B.u1[i], b = B.u2[i];
+    if (MODE == 1)
+        warp_at(W.I0, W.I1, W.I1x, W.I1y, a, b, x, y, B.rows, B.cols, W.I1wx, W.I1wy, W.grad, W.rho_c);
+    if (MODE == 2)
+        flow_uv[i] = make_float2(a, b);
 }
 
-__global__ void k_zero_guarded(float* __restrict__ dst, size_t count, Guard guard)
+// What opens a level, one thread per pixel: the centred gradient of I1, p = 0, and the starting flow - the flow of
+// the level before brought up to this one (upsample_at), or zero on the coarsest level (s1 null).
+__global__ void k_open_level(const float* __restrict__ I1, int rows, int cols, float* __restrict__ dx,
+                             float* __restrict__ dy, float* __restrict__ p, const float* __restrict__ s1,
+                             const float* __restrict__ s2, int srows, int scols, float* __restrict__ d1,
+                             float* __restrict__ d2, Guard guard)
 {
     if (stopped(guard))
         return;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
-        dst[i] = 0.0f;
-}
-
-__global__ void k_merge2_guarded(const float* __restrict__ u, const float* __restrict__ v, size_t count,
-                                 float2* __restrict__ uv, Guard guard)
-{
-    if (stopped(guard))
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= cols || y >= rows)
         return;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count)
-        uv[i] = make_float2(u[i], v[i]);
+    const size_t n = (size_t)rows * cols, i = (size_t)y * cols + x;
+    {
+        const int xm = x > 0 ? x - 1 : 0, xp = x < cols - 1 ? x + 1 : cols - 1;
+        const int ym = y > 0 ? y - 1 : 0, yp = y < rows - 1 ? y + 1 : rows - 1;
+        dx[i] = 0.5f * (I1[(size_t)y * cols + xp] - I1[(size_t)y * cols + xm]);
+        dy[i] = 0.5f * (I1[(size_t)yp * cols + x] - I1[(size_t)ym * cols + x]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        p[j * n + i] = 0.0f;
+    if (!s1)
+    {
+        d1[i] = 0.0f, d2[i] = 0.0f;
+        return;
+    }
+    upsample_at(s1, s2, srows, scols, d1, d2, rows, cols, x, y);
 }
 
 inline dim3 grid2(int cols, int rows, dim3 b)
@@ -1297,10 +1328,10 @@ int Tvl1::calc_gray(const float* I0, const float* I1, int rows, int cols, const 
             return rc;
         if (int rc = L.I1.reserve((size_t)r * c * sizeof(float)))
             return rc;
-        hipLaunchKernelGGL(k_pyr_down, grid2(c, r, b2), b2, 0, st, m.lv[s - 1].I0.as<float>(), m.lv[s - 1].rows,
-                           m.lv[s - 1].cols, L.I0.as<float>(), r, c);
-        hipLaunchKernelGGL(k_pyr_down, grid2(c, r, b2), b2, 0, st, m.lv[s - 1].I1.as<float>(), m.lv[s - 1].rows,
-                           m.lv[s - 1].cols, L.I1.as<float>(), r, c);
+        dim3 g2 = grid2(c, r, b2);
+        g2.z = 2;
+        hipLaunchKernelGGL(k_pyr_down, g2, b2, 0, st, m.lv[s - 1].I0.as<float>(), m.lv[s - 1].I1.as<float>(),
+                           m.lv[s - 1].rows, m.lv[s - 1].cols, L.I0.as<float>(), L.I1.as<float>(), r, c);
         SRX_LAUNCH_CHECK("pyr_down");
     }
     for (int s = 0; s < nscales; ++s)
@@ -1434,53 +1465,49 @@ int Tvl1::calc_gray(const float* I0, const float* I1, int rows, int cols, const 
             hipLaunchKernelGGL((k_tvl1_multi<8, 16, 16, 1024>), gm, dim3(1024), 0, st, P, R, C, l_t, theta, taut, ph.err,
                                iters, first, count, ph.thr, g);
     };
-    // what stands between phase k - 1 and phase k: the gate, the settling of phase k - 1's result into buffer set 0
-    // and, at the first warp of a level, the flow of the level before brought up to this one
-    auto launch_between = [&](int k) {
-        const Phase& prev = plan[(size_t)k - 1];
-        Impl::Level& L = m.lv[prev.s];
-        hipLaunchKernelGGL(k_phase_gate, dim3(1), dim3(64), 0, st, prev.err, prev.n_enq, prev.kt, iters, prev.thr, dstop, k);
-        const Guard g{dstop, k};
-        const unsigned blocks = (unsigned)std::min<size_t>((6 * prev.n + 255) / 256, 2048);
-        hipLaunchKernelGGL(k_settle, dim3(blocks), dim3(256), 0, st, prev.err, prev.kt, iters, prev.thr, L.u1.as<float>(),
-                           L.u2.as<float>(), m.u_alt.as<float>(), m.p.as<float>(), m.p_alt.as<float>(), prev.n, g);
-        if (k == n_phases)
+    // What stands between phase k - 1 and phase k and opens phase k.  Within a level: one launch (gate, settling,
+    // warp).  Between levels: gate and settling, then the new level's gradient, p = 0 and starting flow, then the
+    // warp (it gathers the gradient around its source, so it waits for the whole plane).  Behind the last phase:
+    // gate, settling and the interleaved result.
+    auto launch_step = [&](int k) {
+        WarpPlanes W{};
+        if (k < n_phases)
         {
-            hipLaunchKernelGGL(k_merge2_guarded, dim3((unsigned)((px0 + 255) / 256)), dim3(256), 0, st, m.lv[0].u1.as<float>(),
-                               m.lv[0].u2.as<float>(), px0, (float2*)flow_uv, g);
+            Impl::Level& N = m.lv[plan[(size_t)k].s];
+            W = WarpPlanes{N.I0.as<float>(), N.I1.as<float>(), m.I1x.as<float>(), m.I1y.as<float>(),
+                           m.I1wx.as<float>(), m.I1wy.as<float>(), m.grad.as<float>(), m.rho_c.as<float>()};
+        }
+        const bool same_level = k > 0 && k < n_phases && plan[(size_t)k].w > 0;
+        if (k > 0)
+        {
+            const Phase& prev = plan[(size_t)k - 1];
+            Impl::Level& L = m.lv[prev.s];
+            const Boundary B{prev.err, prev.n_enq, prev.kt, iters, prev.thr, dstop, k, L.u1.as<float>(), L.u2.as<float>(),
+                             m.u_alt.as<float>(), m.p.as<float>(), m.p_alt.as<float>(), prev.R, prev.C};
+            const dim3 g2 = grid2(prev.C, prev.R, b2);
+            if (k == n_phases)
+                hipLaunchKernelGGL(k_boundary<2>, g2, b2, 0, st, B, W, (float2*)flow_uv);
+            else if (same_level)
+                hipLaunchKernelGGL(k_boundary<1>, g2, b2, 0, st, B, W, (float2*)nullptr);
+            else
+                hipLaunchKernelGGL(k_boundary<0>, g2, b2, 0, st, B, W, (float2*)nullptr);
+        }
+        if (k == n_phases || same_level)
             return;
-        }
-        if (plan[(size_t)k].w == 0)
-        {
-            Impl::Level& F = m.lv[plan[(size_t)k].s];
-            hipLaunchKernelGGL(k_upsample_flow, grid2(F.cols, F.rows, b2), b2, 0, st, L.u1.as<float>(), L.u2.as<float>(), L.rows,
-                               L.cols, F.u1.as<float>(), F.u2.as<float>(), F.rows, F.cols, g);
-        }
-    };
-    // what opens phase k: at the first warp of a level the gradient of I1 and p = 0, then the warp
-    auto launch_opening = [&](int k) {
         const Phase& ph = plan[(size_t)k];
-        Impl::Level& L = m.lv[ph.s];
+        Impl::Level& N = m.lv[ph.s];
         const Guard g{dstop, k};
         const dim3 g2 = grid2(ph.C, ph.R, b2);
-        if (ph.w == 0)
-        {
-            hipLaunchKernelGGL(k_centered_gradient, g2, b2, 0, st, L.I1.as<float>(), ph.R, ph.C, m.I1x.as<float>(),
-                               m.I1y.as<float>(), g);
-            const unsigned blocks = (unsigned)std::min<size_t>((4 * ph.n + 255) / 256, 2048);
-            hipLaunchKernelGGL(k_zero_guarded, dim3(blocks), dim3(256), 0, st, m.p.as<float>(), 4 * ph.n, g);
-        }
-        hipLaunchKernelGGL(k_warp, g2, b2, 0, st, L.I0.as<float>(), L.I1.as<float>(), m.I1x.as<float>(), m.I1y.as<float>(),
-                           L.u1.as<float>(), L.u2.as<float>(), ph.R, ph.C, m.I1wx.as<float>(), m.I1wy.as<float>(),
-                           m.grad.as<float>(), m.rho_c.as<float>(), g);
+        const Impl::Level* below = k > 0 ? &m.lv[plan[(size_t)k - 1].s] : nullptr;
+        hipLaunchKernelGGL(k_open_level, g2, b2, 0, st, N.I1.as<float>(), ph.R, ph.C, m.I1x.as<float>(), m.I1y.as<float>(),
+                           m.p.as<float>(), below ? below->u1.as<float>() : (const float*)nullptr,
+                           below ? below->u2.as<float>() : (const float*)nullptr, below ? below->rows : 0,
+                           below ? below->cols : 0, N.u1.as<float>(), N.u2.as<float>(), g);
+        hipLaunchKernelGGL(k_warp, g2, b2, 0, st, W.I0, W.I1, W.I1x, W.I1y, N.u1.as<float>(), N.u2.as<float>(), ph.R, ph.C,
+                           W.I1wx, W.I1wy, W.grad, W.rho_c, g);
     };
 
     SRX_HIP(hipMemsetAsync(derr, 0, (err_words + 1) * sizeof(unsigned long long), st));
-    {
-        const size_t n = (size_t)m.lv[nscales - 1].rows * m.lv[nscales - 1].cols * sizeof(float);
-        SRX_HIP(hipMemsetAsync(m.lv[nscales - 1].u1.get(), 0, n, st));
-        SRX_HIP(hipMemsetAsync(m.lv[nscales - 1].u2.get(), 0, n, st));
-    }
     // Launches of a phase queued at first: what the same phase of the previous pair needed (consecutive pairs of a
     // stream converge alike) and a margin; launches queued beyond the converged iteration return at once.  The host
     // looks once, behind the whole chain; a chain that stopped at some phase is continued from there.
@@ -1507,12 +1534,10 @@ int Tvl1::calc_gray(const float* I0, const float* I1, int rows, int cols, const 
         }
         for (int k = resume; k <= n_phases; ++k)
         {
-            if (k > 0)
-                launch_between(k);
+            launch_step(k);
             if (k == n_phases)
                 break;
             Phase& ph = plan[(size_t)k];
-            launch_opening(k);
             ph.n_enq = first_batch(ph, std::max(m.last_done[(size_t)k], m.before_last_done[(size_t)k]));
             for (int b = 0; b < ph.n_enq; ++b)
                 launch_iterations(ph, k, b);
