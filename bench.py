@@ -85,6 +85,9 @@ def parse():
                     help="do not bracket the solver kernels with HIP events (the roofline object is then left out)")
     ap.add_argument("--cpu-iters", type=int, default=12, help="iterations of the CPU sample solve")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when this process starts the ranks")
+    ap.add_argument("--growing-rotation", action="store_true",
+                    help="stress clip: the camera's rotation amplitude grows with the square root of the frame index "
+                         "(corner displacements of tens of HR pixels between neighbouring frames late in the clip)")
     ap.add_argument("--pairs-in-flight", type=int, default=3,
                     help="tvl1 workload: independent frame pairs the library works on side by side (1 .. 4)")
     ap.add_argument("--pairs-per-step", type=int, default=0,
@@ -319,7 +322,7 @@ def bench_solver(args):
     total = n_own * world
     a, b, in_first, in_last = spans.span_plan(total, r, world, rank)
     assert b - a + 1 == n_own
-    cams = synth.camera_path(total + 2 * r + 2, seed=1234)
+    cams = synth.camera_path(total + 2 * r + 2, seed=1234, rot_growth=args.growing_rotation)
 
     def frame(t):
         hr = synth.ground_truth_frame(cams[t], args.rows * s, args.cols * s, args.channels, 1234, dev)
@@ -427,7 +430,8 @@ def bench_solver(args):
                             f"temporalAreaRadius {r} (window {K}), streaming nextFrame(), motion: "
                             + ("exact synthetic flow (dry run)" if R.dry else
                                {"tvl1": "built-in TV-L1 flow", "farneback": "built-in Farneback flow"}.get(
-                                   args.flow, "exact synthetic flow resident in HBM")),
+                                   args.flow, "exact synthetic flow resident in HBM"))
+                            + (" (stress clip: rotation amplitude growing along the clip)" if args.growing_rotation else ""),
                 "frames_per_gpu": args.steps,
                 "io": "host frames in, host frames out (PCIe inclusive)" if args.host_io else "frames resident in HBM",
                 "read_ahead": read_ahead,
@@ -531,7 +535,7 @@ def bench_strong(args):
         sys.exit(2)
     a, b, in_first, in_last = spans.span_plan(total, r, world, rank)
     n_own = b - a + 1
-    cams = synth.camera_path(total, seed=1234)
+    cams = synth.camera_path(total, seed=1234, rot_growth=args.growing_rotation)
 
     def frame(t):
         hr = synth.ground_truth_frame(cams[t], args.rows * s, args.cols * s, args.channels, 1234, dev)

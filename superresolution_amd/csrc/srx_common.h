@@ -119,7 +119,14 @@ int launch_sign_unpair(const uint32_t* pairs, uint32_t* plain, int lr_rows, int 
 int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const PtrList& raw_bwd,
                         const PtrList* dec_bwd, const PtrList& y, const MutPtrList& signs, int K, int scale,
                         const GaussK& g, size_t generic_plane_stride, hipStream_t st,
-                        const PtrList* y_bytes = nullptr, int still_frame = -1);
+                        const PtrList* y_bytes = nullptr, int still_frame = -1, const void* tile_plan = nullptr);
+// The specialised scale-4 forward kernel's tiles cut by the cost of their rows (rows whose gathers leave the
+// kernel's LDS window are slow): launch_plan_forward_tiles reads the row kinds that launch_build_maps left behind
+// the K frames' decoded backward maps and writes the plan (forward_plan_bytes; scratch of *scratch_bytes) that
+// launch_forward_sign then takes as tile_plan.  *planned = false: no plan was made (tiny images), pass nullptr.
+size_t forward_plan_bytes(int hr_rows, int hr_cols, int ch, int K, size_t* scratch_bytes);
+int launch_plan_forward_tiles(const PtrList& dec_bwd, int K, int hr_rows, int hr_cols, int ch, void* plan, void* scratch,
+                              bool* planned, hipStream_t st);
 // With dec_fwd (and an eligible parameter set) the specialised kernel runs; it
 // wants X and X_out planar and the signs as pair planes (sign_pair_bytes).
 // identity_frame (-1 = none): a frame whose forward map is known to be the identity (zero motion: the base frame

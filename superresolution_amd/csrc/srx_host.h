@@ -160,6 +160,7 @@ class Solver
     int ensure(int K, int rows, int cols, int ch, int scale, hipStream_t st);
     std::vector<DeviceBuffer> fwd_maps_, bwd_maps_, dec_fwd_, dec_bwd_, signs_, rel_;
     DeviceBuffer x_[2];
+    DeviceBuffer tile_plan_, tile_cost_; // the forward kernel's tiles for the current window's maps
     const uint8_t* y8_[kMaxWindow] = {};
     int y8_count_ = 0;
     int still_frame_ = -1; // window frame whose relative motion process() has just set to zero (else -1)

@@ -473,6 +473,9 @@ static_assert(kFwdMx % 4 == 0, "staged columns start at a multiple of four");
 // pixels onto themselves (zero motion: the base frame of a window, a static scene), so that the kernel
 // needs no entry at all.  One wave per (strip, LR row); lanes as in the forward kernel.
 constexpr uint8_t kRowMixed = 0, kRowInside = 1, kRowOutside = 2, kRowIdentity = 3;
+// beside the kind (the low two bits): some lane of a mixed row has a source outside the window, i.e. the row makes
+// a trip to global memory (a mixed row without it only needs the long form of the entries)
+constexpr uint8_t kRowKindMask = 3, kRowLeaves = 4;
 __global__ void k_group_flags(const uint32_t* __restrict__ grp, uint8_t* __restrict__ flags, int H, int W, int strips_x)
 {
     const int w = W >> 2, h = H >> 2;
@@ -483,7 +486,7 @@ __global__ void k_group_flags(const uint32_t* __restrict__ grp, uint8_t* __restr
     const size_t entries = (size_t)h * w * 4;
     // ok: every group of the lane lies in the window by its short entry (then the long one says the same);
     // any: some group does by its long entry
-    bool ok = true, any = false, same = true;
+    bool ok = true, any = false, every = true, same = true;
     for (int r = 0; r < 4; ++r)
     {
         const size_t e = ((size_t)y * w + xl) * 4 + r;
@@ -506,13 +509,16 @@ __global__ void k_group_flags(const uint32_t* __restrict__ grp, uint8_t* __restr
         }
         ok = ok && in_s;
         any = any || in_l;
+        every = every && in_l;
     }
     const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
     const bool all_same = all_ok && __builtin_amdgcn_ballot_w64(!same) == 0;
     const int n_in = __builtin_popcountll(__builtin_amdgcn_ballot_w64(any));
+    const bool leaves = __builtin_amdgcn_ballot_w64(!every) != 0;
     if (lane == 0)
         flags[(size_t)y * strips_x + strip] =
-            all_same ? kRowIdentity : (all_ok ? kRowInside : (n_in < 48 ? kRowOutside : kRowMixed));
+            all_same ? kRowIdentity
+                     : (all_ok ? kRowInside : (n_in < 48 ? kRowOutside : (leaves ? kRowMixed | kRowLeaves : kRowMixed)));
 }
 
 // k_build_maps, k_group_maps and k_group_flags in one pass (scale 4): a thread works on one LR cell - the 4 x 4 HR
@@ -690,7 +696,7 @@ __global__ __launch_bounds__(64) void k_build_maps_cells(const float* __restrict
     }
     // the row's kind (k_group_flags), from the entries just made
     const int dc_lane = 4 * xl - (4 * (x0 - 1) - kFwdMx);
-    bool ok = true, any = false, same = true;
+    bool ok = true, any = false, every = true, same = true;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
     {
@@ -715,13 +721,16 @@ __global__ __launch_bounds__(64) void k_build_maps_cells(const float* __restrict
         }
         ok = ok && in_s;
         any = any || in_l;
+        every = every && in_l;
     }
     const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
     const bool all_same = all_ok && __builtin_amdgcn_ballot_w64(!same) == 0;
     const int n_in = __builtin_popcountll(__builtin_amdgcn_ballot_w64(any));
+    const bool leaves = __builtin_amdgcn_ballot_w64(!every) != 0;
     if (lane == 0)
         flags[(size_t)y * strips_x + strip] =
-            all_same ? kRowIdentity : (all_ok ? kRowInside : (n_in < 48 ? kRowOutside : kRowMixed));
+            all_same ? kRowIdentity
+                     : (all_ok ? kRowInside : (n_in < 48 ? kRowOutside : (leaves ? kRowMixed | kRowLeaves : kRowMixed)));
 }
 
 // ps == 0: interleaved destination; otherwise planar with plane stride ps
@@ -1219,6 +1228,127 @@ template <int N> struct __attribute__((packed, aligned(4))) packed_floats
 #define SRX_A2_WAVES 3
 #endif
 
+// Tiles of the forward kernel cut by what their rows cost.  A tile's LR rows move at the pace of the slowest wave
+// (one barrier per LR row), and a row with gathers that leave the LDS window (a few lanes: kRowMixed with
+// kRowLeaves, most lanes: kRowOutside) goes to global memory for them and takes longer; with an even cut the few tiles that hold such
+// rows (image corners under a rotation, a border under a pan) finish long after the others, and the launch - one
+// tile per CU - ends with them.  Here every (LR row, strip) gets a cost: that of a row served from the window plus
+// a surcharge per frame whose wave goes to global memory there (such waves share the CU's path to the caches, so
+// the row's time grows with their number); strips get tiles in proportion to their cost (bisection on the cost per tile, a tile's start-up
+// included), and a strip's rows are cut where the running cost passes the next multiple of the strip's share.
+// Which rows a tile holds never changes a value.  One block, a wave per strip; plan[t] = (strip, first row, end
+// row, 0); spare entries and tiles that a single costly row left without rows have first row == end row.
+constexpr int kPlanThreads = 1024, kPlanMaxStrips = 256;
+constexpr int kPlanPerTile = 80; // a tile's start-up in units of PlanCost (five rows served from the window)
+struct PlanCost
+{
+    int inside, mixed, outside, most_extra, min_rows;
+};
+__global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(PtrList grp_bwd, int K, int H, int W, int strips_x,
+                                                             int n_tiles, PlanCost pc, int* __restrict__ cost,
+                                                             int4* __restrict__ plan)
+{
+    __shared__ int s_total[kPlanMaxStrips], s_first[kPlanMaxStrips + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = H >> 2;
+    const size_t flag_at = 3 * ((size_t)H * W / 4) * sizeof(uint32_t);
+    for (int i = tid; i < h * strips_x; i += kPlanThreads)
+    {
+        int extra = 0;
+        for (int k = 0; k < K; ++k)
+        {
+            const uint8_t flag = ((const uint8_t*)grp_bwd.p[k] + flag_at)[i];
+            extra += (flag & kRowKindMask) == kRowOutside ? pc.outside : ((flag & kRowLeaves) ? pc.mixed : 0);
+        }
+        cost[i] = pc.inside + min(extra, pc.most_extra);
+    }
+    for (int t = tid; t < n_tiles; t += kPlanThreads)
+        plan[t] = make_int4(0, 0, 0, 0);
+    __syncthreads();
+    // a lane owns `chunk` neighbouring rows of its wave's strip
+    const int chunk = (h + 63) / 64;
+    const int ya = min(lane * chunk, h), yb = min(ya + chunk, h);
+    for (int sidx = wave; sidx < strips_x; sidx += kPlanThreads / 64)
+    {
+        int part = 0;
+        for (int y = ya; y < yb; ++y)
+            part += cost[y * strips_x + sidx];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            part += __shfl_xor(part, o, 64);
+        if (lane == 0)
+            s_total[sidx] = part;
+    }
+    __syncthreads();
+    // the smallest cost per tile L (start-up included) at which the strips need no more than n_tiles tiles:
+    // tiles(s, L) = ceil(total_s / (L - kPlanPerTile)), at least 1 and at most h / min_rows; every thread runs the
+    // same search
+    const int most = max(1, h / max(pc.min_rows, 1));
+    int lo = kPlanPerTile + 1, hi = kPlanPerTile + 1;
+    for (int sidx = 0; sidx < strips_x; ++sidx)
+        hi = max(hi, kPlanPerTile + s_total[sidx]);
+    while (lo < hi)
+    {
+        const int mid = lo + (hi - lo) / 2;
+        int need = 0;
+        for (int sidx = 0; sidx < strips_x; ++sidx)
+            need += min(most, max(1, (s_total[sidx] + (mid - kPlanPerTile) - 1) / (mid - kPlanPerTile)));
+        if (need <= n_tiles)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    const int share = lo - kPlanPerTile;
+    if (tid == 0)
+    {
+        int at = 0;
+        for (int sidx = 0; sidx < strips_x; ++sidx)
+        {
+            s_first[sidx] = at;
+            at += min(most, max(1, (s_total[sidx] + share - 1) / share));
+        }
+        s_first[strips_x] = at; // <= n_tiles
+    }
+    __syncthreads();
+    int* const fields = (int*)plan;
+    for (int sidx = wave; sidx < strips_x; sidx += kPlanThreads / 64)
+    {
+        const int first = s_first[sidx], T = s_first[sidx + 1] - first;
+        const long long total = max(s_total[sidx], 1);
+        for (int j = lane; j < T; j += 64)
+            fields[4 * (first + j)] = sidx;
+        if (lane == 0)
+        {
+            fields[4 * first + 1] = 0;
+            fields[4 * (first + T - 1) + 2] = h;
+        }
+        // running cost in front of the lane's rows
+        int part = 0;
+        for (int y = ya; y < yb; ++y)
+            part += cost[y * strips_x + sidx];
+        int before = part;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1)
+        {
+            const int v = __shfl_up(before, o, 64);
+            if (lane >= o)
+                before += v;
+        }
+        long long acc = before - part;
+        // tile j of the strip starts behind the first row at which the running cost reaches j shares
+        for (int y = ya; y < yb; ++y)
+        {
+            const long long next = acc + cost[y * strips_x + sidx];
+            const int j0 = (int)(acc * T / total), j1 = (int)min((long long)T - 1, next * T / total);
+            for (int j = j0 + 1; j <= j1; ++j)
+            {
+                fields[4 * (first + j) + 1] = y + 1;
+                fields[4 * (first + j - 1) + 2] = y + 1;
+            }
+            acc = next;
+        }
+    }
+}
+
 inline size_t forward_lds_bytes(int ch)
 {
     return (size_t)kFwdRing * ch * kFwdRowBytes;
@@ -1228,7 +1358,7 @@ inline size_t forward_lds_bytes(int ch)
 template <int CH, bool Y8>
 __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sign_lds(
     const float* __restrict__ X, int H, int W, size_t ps, PtrList raw_bwd, PtrList grp_bwd, PtrList ys, MutPtrList signs,
-    int K, GaussK g, int strips_x, int rows_per_tile, unsigned n_tiles, int frame_shift)
+    int K, GaussK g, int strips_x, int rows_per_tile, unsigned n_tiles, int frame_shift, const int4* __restrict__ plan)
 {
     extern __shared__ __align__(16) char ring[];
     constexpr int kSlotBytes = CH * kFwdRowBytes;
@@ -1243,7 +1373,15 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
         return;
     if ((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring != 0u)
         __builtin_trap(); // the gathers below address the ring by offset
-    const int strip = tile % strips_x, rg = tile / strips_x;
+    // the tile's strip and rows: an even cut of the rows, or what k_plan_tiles laid down
+    int strip = tile % strips_x, tile_y0 = (tile / strips_x) * rows_per_tile, tile_y1 = tile_y0 + rows_per_tile;
+    if (plan)
+    {
+        const int4 t = plan[tile];
+        strip = t.x, tile_y0 = t.y, tile_y1 = t.z;
+        if (tile_y0 >= tile_y1)
+            return; // a spare entry (the whole block leaves before any barrier)
+    }
     const int h = H >> 2, w = W >> 2;
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
     const int kw = blockIdx.y * (nthreads >> 6) + (tid >> 6);
@@ -1254,8 +1392,8 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
     // motion (the cheapest one: no map entries, no address arithmetic) goes to the last wave, which in a block
     // of 4n+1 waves sits on the SIMD that carries a wave more than the others.
     const int k = __builtin_amdgcn_readfirstlane(active ? (kw + frame_shift >= K ? kw + frame_shift - K : kw + frame_shift) : 0);
-    const int x0 = strip * kFwdStrip, y0 = rg * rows_per_tile;
-    const int y1 = min(y0 + rows_per_tile, h);
+    const int x0 = strip * kFwdStrip, y0 = tile_y0;
+    const int y1 = min(tile_y1, h);
 
     const int x = x0 - 1 + lane;          // LR column of this lane
     const int xl = min(max(x, 0), w - 1); // column it loads (clamped copies are never stored)
@@ -1574,7 +1712,7 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
     // The kinds of the tile's rows, 64 rows at a time, one per lane: a load per row would put a memory
     // latency in front of every row (the kind decides the row's code path).
     uint32_t kinds = flags[(size_t)min(y0 + lane, h - 1) * strips_x];
-    uint8_t place = (uint8_t)__builtin_amdgcn_readlane((int)kinds, 0);
+    uint8_t place = (uint8_t)(__builtin_amdgcn_readlane((int)kinds, 0) & kRowKindMask);
     load_groups(y0, place, mc);
     uint32_t sg_above = 0; // sign word of the LR row before the current one
 #ifdef SRX_STAMPS
@@ -1591,7 +1729,7 @@ __global__ __launch_bounds__(64 * kFwdMaxWaves, SRX_A2_WAVES) void k_forward_sig
         const int ahead = y + 1 - y0; // row y + 1 within the tile
         if ((ahead & 63) == 0)
             kinds = flags[(size_t)min(y + 1 + lane, h - 1) * strips_x];
-        const uint8_t place_next = (uint8_t)__builtin_amdgcn_readlane((int)kinds, ahead & 63);
+        const uint8_t place_next = (uint8_t)(__builtin_amdgcn_readlane((int)kinds, ahead & 63) & kRowKindMask);
         float4 sv[kSlots];
         batch_load(more ? 4 * y + 3 + kFwdMy : H, sv);
         uint2 mn[4];
@@ -2940,9 +3078,103 @@ bool forward_fast_eligible(int hr_rows, int hr_cols, int ch, int scale, const Ga
            hr_rows <= kGrpMaxDim && hr_cols <= kGrpMaxDim && (size_t)ch * (hr_px + 4) * sizeof(float) < 0x7FFFFFF0u;
 }
 
+// CUs of the current device and, on first use per device, the forward kernel's dynamic-LDS limit (a per-device
+// attribute); 0 with the error set
+static int forward_device_setup()
+{
+    constexpr int kMaxDevices = 64;
+    static std::atomic<int> cus_of[kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices)
+    {
+        check_launch("forward_sign_lds (device query)");
+        return 0;
+    }
+    int cus = cus_of[dev].load(std::memory_order_acquire);
+    if (cus == 0)
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess)
+        {
+            check_launch("forward_sign_lds (device query)");
+            return 0;
+        }
+        if (hipFuncSetAttribute((const void*)k_forward_sign_lds<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)forward_lds_bytes(1)) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_forward_sign_lds<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)forward_lds_bytes(3)) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_forward_sign_lds<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)forward_lds_bytes(1)) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_forward_sign_lds<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)forward_lds_bytes(3)) != hipSuccess)
+        {
+            check_launch("forward_sign_lds (LDS size)");
+            return 0;
+        }
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        cus_of[dev].store(cus, std::memory_order_release);
+    }
+    return cus;
+}
+
+// Tiles of one launch of k_forward_sign_lds: as many as one round of resident blocks holds
+static int forward_tile_slots(int ch, int K, int cus)
+{
+    const int passes = (K + kFwdMaxWaves - 1) / kFwdMaxWaves;
+    const int blocks_per_cu = forward_lds_bytes(ch) * 2 <= 160 * 1024 ? 2 : 1;
+    return std::max(1, blocks_per_cu * cus / passes);
+}
+
+// Cost of a row served from the window, surcharge per frame with a mixed row that leaves the window and per frame
+// with an outside row, the most all surcharges of a row add up to, bound on the tiles per strip (rows / min_rows);
+// tuning aid:
+// SRX_FWD_PLAN="inside,mixed,outside,most_extra,min_rows" in the environment replaces them (read once; inside = 0
+// turns the plan off)
+static PlanCost g_plan_cost = [] {
+    // (measured on clips with exact and with TV-L1 motion: a row costs about twice as much once any frame's wave
+    // leaves the window, and hardly more when several do)
+    PlanCost pc{16, 16, 16, 16, 4};
+    if (const char* e = std::getenv("SRX_FWD_PLAN"))
+    {
+        int v[5];
+        if (std::sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) == 5 && v[0] >= 0 && v[4] >= 1)
+            pc = PlanCost{v[0], v[1], v[2], v[3], v[4]};
+    }
+    return pc;
+}();
+
+size_t forward_plan_bytes(int hr_rows, int hr_cols, int ch, int K, size_t* scratch_bytes)
+{
+    const int w = hr_cols / 4, h = hr_rows / 4;
+    const int strips_x = (w + kFwdStrip - 1) / kFwdStrip;
+    if (scratch_bytes)
+        *scratch_bytes = (size_t)h * strips_x * sizeof(int);
+    // room for any device this build runs on (the tile count follows the CU count)
+    return (size_t)std::max(forward_tile_slots(ch, K, 1024), strips_x) * sizeof(int4);
+}
+
+int launch_plan_forward_tiles(const PtrList& dec_bwd, int K, int hr_rows, int hr_cols, int ch, void* plan, void* scratch,
+                              bool* planned, hipStream_t st)
+{
+    *planned = false;
+    const int w = hr_cols / 4, h = hr_rows / 4;
+    const int strips_x = (w + kFwdStrip - 1) / kFwdStrip;
+    const int cus = forward_device_setup();
+    if (cus == 0)
+        return 1;
+    const int n_tiles = forward_tile_slots(ch, K, cus);
+    if (g_plan_cost.inside <= 0 || strips_x > n_tiles || strips_x > kPlanMaxStrips || K < 1 || K > kMaxWindow)
+        return 0; // the even cut
+    hipLaunchKernelGGL(k_plan_tiles, dim3(1), dim3(kPlanThreads), 0, st, dec_bwd, K, hr_rows, hr_cols, strips_x, n_tiles,
+                       g_plan_cost, (int*)scratch, (int4*)plan);
+    *planned = true;
+    return check_launch("plan_tiles");
+}
+
 int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const PtrList& raw_bwd,
                         const PtrList* dec_bwd, const PtrList& y, const MutPtrList& signs, int K, int scale,
-                        const GaussK& g, size_t generic_plane_stride, hipStream_t st, const PtrList* y_bytes, int still_frame)
+                        const GaussK& g, size_t generic_plane_stride, hipStream_t st, const PtrList* y_bytes, int still_frame,
+                        const void* tile_plan)
 {
     if (ch != 1 && ch != 3)
     {
@@ -2957,36 +3189,16 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
         // one wave per window frame, at most kFwdMaxWaves frames per block (more frames: more passes)
         const int passes = (K + kFwdMaxWaves - 1) / kFwdMaxWaves;
         const int waves = (K + passes - 1) / passes;
-        // cut the rows so that one round of resident blocks covers the image
-        // per device, set up on first use: CU count and the kernels' dynamic-LDS limit (a per-device attribute)
-        constexpr int kMaxDevices = 64;
-        static std::atomic<int> cus_of[kMaxDevices];
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices)
-            return check_launch("forward_sign_lds (device query)");
-        int cus = cus_of[dev].load(std::memory_order_acquire);
+        // cut the rows so that one round of resident blocks covers the image (evenly, or as planned)
+        const int cus = forward_device_setup();
         if (cus == 0)
-        {
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, dev) != hipSuccess)
-                return check_launch("forward_sign_lds (device query)");
-            if (hipFuncSetAttribute((const void*)k_forward_sign_lds<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)forward_lds_bytes(1)) != hipSuccess ||
-                hipFuncSetAttribute((const void*)k_forward_sign_lds<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)forward_lds_bytes(3)) != hipSuccess ||
-                hipFuncSetAttribute((const void*)k_forward_sign_lds<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)forward_lds_bytes(1)) != hipSuccess ||
-                hipFuncSetAttribute((const void*)k_forward_sign_lds<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)forward_lds_bytes(3)) != hipSuccess)
-                return check_launch("forward_sign_lds (LDS size)");
-            cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-            cus_of[dev].store(cus, std::memory_order_release);
-        }
-        const int blocks_per_cu = forward_lds_bytes(ch) * 2 <= 160 * 1024 ? 2 : 1;
-        const int slots = std::max(1, blocks_per_cu * cus / (strips_x * passes));
+            return 1;
+        const int slots_all = forward_tile_slots(ch, K, cus);
+        const int slots = std::max(1, slots_all / strips_x);
         const int rows_per_tile = std::max(4, (h + slots - 1) / slots);
         const int row_groups = (h + rows_per_tile - 1) / rows_per_tile;
-        const unsigned n_tiles = (unsigned)strips_x * row_groups;
+        const int4* plan = (const int4*)tile_plan;
+        const unsigned n_tiles = plan ? (unsigned)slots_all : (unsigned)strips_x * row_groups;
         const dim3 gr(xcd_grid(n_tiles), passes), b(64 * waves);
         const size_t lds = forward_lds_bytes(ch);
         // the still frame goes to the last wave of the (single) pass
@@ -2995,17 +3207,17 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
         {
             if (ch == 1)
                 hipLaunchKernelGGL((k_forward_sign_lds<1, true>), gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd,
-                                   *y_bytes, signs, K, g, strips_x, rows_per_tile, n_tiles, shift);
+                                   *y_bytes, signs, K, g, strips_x, rows_per_tile, n_tiles, shift, plan);
             else
                 hipLaunchKernelGGL((k_forward_sign_lds<3, true>), gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd,
-                                   *y_bytes, signs, K, g, strips_x, rows_per_tile, n_tiles, shift);
+                                   *y_bytes, signs, K, g, strips_x, rows_per_tile, n_tiles, shift, plan);
         }
         else if (ch == 1)
             hipLaunchKernelGGL((k_forward_sign_lds<1, false>), gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd, y,
-                               signs, K, g, strips_x, rows_per_tile, n_tiles, shift);
+                               signs, K, g, strips_x, rows_per_tile, n_tiles, shift, plan);
         else
             hipLaunchKernelGGL((k_forward_sign_lds<3, false>), gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd, y,
-                               signs, K, g, strips_x, rows_per_tile, n_tiles, shift);
+                               signs, K, g, strips_x, rows_per_tile, n_tiles, shift, plan);
         return check_launch("forward_sign_lds");
     }
     if (g_kernel_path == 0 && scale == 2 && g.n == 5 && generic_plane_stride != 0 && hr_cols >= 8 && hr_rows >= 8 &&

@@ -301,6 +301,8 @@ void Solver::release()
     rel_.clear();
     x_[0].release();
     x_[1].release();
+    tile_plan_.release();
+    tile_cost_.release();
     tables_ = CubicTablesDev();
 }
 
@@ -384,6 +386,22 @@ int Solver::run(const float* const* y, const float* const* rel, int K, int base_
         sgm.p[k] = signs_[k].get();
     }
 
+    // the forward kernel's tiles, cut by what the rows of this window's maps cost
+    const void* tile_plan = nullptr;
+    if (fastA)
+    {
+        size_t scratch_bytes = 0;
+        const size_t plan_bytes = forward_plan_bytes((int)R, (int)C, ch, K, &scratch_bytes);
+        if (int rc = tile_plan_.reserve(plan_bytes))
+            return rc;
+        if (int rc = tile_cost_.reserve(scratch_bytes))
+            return rc;
+        bool planned = false;
+        if (int rc = launch_plan_forward_tiles(dbwd, K, (int)R, (int)C, ch, tile_plan_.get(), tile_cost_.get(), &planned, st))
+            return rc;
+        tile_plan = planned ? tile_plan_.get() : nullptr;
+    }
+
     // initial estimation (lib/src/btv_l1.cpp:412)
     cur_ = 0;
     if (int rc = launch_resize_cubic(y[base_idx], rows, cols, ch, t, x_[0].as<float>(), (int)R, (int)C, ps_, st))
@@ -409,7 +427,7 @@ int Solver::run(const float* const* y, const float* const* rel, int K, int base_
         if (time_it)
             SRX_HIP(hipEventRecord(events_[3 * timed], st));
         if (int rc = launch_forward_sign(x_[cur_].as<float>(), (int)R, (int)C, ch, bwd, fastA ? &dbwd : nullptr, ys,
-                                         sgm, K, s, gauss_, ps_, st, have_bytes ? &ys8 : nullptr, still))
+                                         sgm, K, s, gauss_, ps_, st, have_bytes ? &ys8 : nullptr, still, tile_plan))
             return rc;
         if (time_it)
             SRX_HIP(hipEventRecord(events_[3 * timed + 1], st));
