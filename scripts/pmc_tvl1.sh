@@ -9,7 +9,7 @@ PAIRS=4
 pmct() { # tag, counters...
   local tag=$1; shift
   rm -rf $O/pmc_$tag
-  timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d $O/pmc_$tag -- python3 $R/bench.py --workload tvl1 --steps $PAIRS --warmup 0 --no-cpu-baseline > $O/pmc_$tag.log 2>&1
+  timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d $O/pmc_$tag -- python3 $R/bench.py --workload tvl1 --pairs-in-flight 1 --pairs-per-step 1 --steps $PAIRS --warmup 0 --no-cpu-baseline > $O/pmc_$tag.log 2>&1
   echo "pmc $tag rc=$?"
 }
 pmct fetcht FETCH_SIZE || exit 1
