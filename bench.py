@@ -82,7 +82,7 @@ def parse():
                     help="hand over host frames and take host output (the PCIe-inclusive rate; never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
-                    help="do not bracket the solver kernels with HIP events (the roofline object is then left out)")
+                    help="do not time the solver kernels with HIP events (the roofline object is then left out)")
     ap.add_argument("--cpu-iters", type=int, default=12, help="iterations of the CPU sample solve")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when this process starts the ranks")
     ap.add_argument("--growing-rotation", action="store_true",

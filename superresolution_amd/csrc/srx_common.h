@@ -120,6 +120,14 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
                         const PtrList* dec_bwd, const PtrList& y, const MutPtrList& signs, int K, int scale,
                         const GaussK& g, size_t generic_plane_stride, hipStream_t st,
                         const PtrList* y_bytes = nullptr, int still_frame = -1, const void* tile_plan = nullptr);
+// Events for the next launch of launch_forward_sign / launch_backproject_update on this thread (both null: none):
+// start is tied to the kernel's begin, stop to its end.  Cleared by the caller after the launch.
+struct LaunchTimer
+{
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+extern thread_local LaunchTimer g_launch_timer;
+
 // The specialised scale-4 forward kernel's tiles cut by the cost of their rows (rows whose gathers leave the
 // kernel's LDS window are slow): launch_plan_forward_tiles reads the row kinds that launch_build_maps left behind
 // the K frames' decoded backward maps and writes the plan (forward_plan_bytes; scratch of *scratch_bytes) that

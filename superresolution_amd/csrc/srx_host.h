@@ -145,8 +145,9 @@ class Solver
     void release();
 
     // Optional per-kernel timing with HIP events on the solver's stream: the forward
-    // and back-projection launches of every kTimingStride-th iteration are bracketed
-    // by events that are read back (after a stream synchronise) by collect_timing().
+    // and back-projection launches of every kTimingStride-th iteration carry a start and
+    // a stop event each (the kernel's own begin and end), read back (after a stream
+    // synchronise) by collect_timing().
     static constexpr int kTimingStride = 8;
     void enable_timing(bool on) { timing_ = on; }
     bool timing() const { return timing_; }
@@ -175,7 +176,7 @@ class Solver
     int curBtvKernelSize_ = -1;
     double curAlpha_ = -1.0;
     bool timing_ = false;
-    std::vector<hipEvent_t> events_; // 3 per iteration of the last run
+    std::vector<hipEvent_t> events_; // 4 per timed iteration of the last run
     int pending_iters_ = 0;
     double fwd_ms_ = 0.0, bwd_ms_ = 0.0;
     long timed_iters_ = 0;

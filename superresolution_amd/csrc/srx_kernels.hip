@@ -40,6 +40,8 @@
 // blur and BTV size 7.
 #include "srx_common.h"
 
+#include <hip/hip_ext.h>
+
 
 #include <atomic>
 #include <cmath>
@@ -3078,6 +3080,25 @@ bool forward_fast_eligible(int hr_rows, int hr_cols, int ch, int scale, const Ga
            hr_rows <= kGrpMaxDim && hr_cols <= kGrpMaxDim && (size_t)ch * (hr_px + 4) * sizeof(float) < 0x7FFFFFF0u;
 }
 
+// A launch of one of the two solver kernels.  With g_launch_timer armed (Solver::run, kernel timing) the launch goes
+// through hipExtLaunchKernelGGL, which ties the two events to the dispatch's own start and end: their distance is
+// the kernel's execution time, as a profiler reports it.  (Events recorded in front of and behind a launch also
+// count the time the queue takes to get from the marker to the kernel.)  The first launch after arming takes the
+// start event, every launch moves the stop event.
+thread_local LaunchTimer g_launch_timer;
+#define SRX_LAUNCH_TIMED(kernel, grid, block, lds, st, ...)                                                            \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (g_launch_timer.stop)                                                                                       \
+        {                                                                                                              \
+            hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)(lds), st, g_launch_timer.start,                 \
+                                  g_launch_timer.stop, 0, __VA_ARGS__);                                                \
+            g_launch_timer.start = nullptr;                                                                            \
+        }                                                                                                              \
+        else                                                                                                           \
+            hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                             \
+    } while (0)
+
 // CUs of the current device and, on first use per device, the forward kernel's dynamic-LDS limit (a per-device
 // attribute); 0 with the error set
 static int forward_device_setup()
@@ -3206,17 +3227,17 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
         if (y_bytes)
         {
             if (ch == 1)
-                hipLaunchKernelGGL((k_forward_sign_lds<1, true>), gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd,
+                SRX_LAUNCH_TIMED((k_forward_sign_lds<1, true>), gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd,
                                    *y_bytes, signs, K, g, strips_x, rows_per_tile, n_tiles, shift, plan);
             else
-                hipLaunchKernelGGL((k_forward_sign_lds<3, true>), gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd,
+                SRX_LAUNCH_TIMED((k_forward_sign_lds<3, true>), gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd,
                                    *y_bytes, signs, K, g, strips_x, rows_per_tile, n_tiles, shift, plan);
         }
         else if (ch == 1)
-            hipLaunchKernelGGL((k_forward_sign_lds<1, false>), gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd, y,
+            SRX_LAUNCH_TIMED((k_forward_sign_lds<1, false>), gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd, y,
                                signs, K, g, strips_x, rows_per_tile, n_tiles, shift, plan);
         else
-            hipLaunchKernelGGL((k_forward_sign_lds<3, false>), gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd, y,
+            SRX_LAUNCH_TIMED((k_forward_sign_lds<3, false>), gr, b, lds, st, X, hr_rows, hr_cols, ps, raw_bwd, *dec_bwd, y,
                                signs, K, g, strips_x, rows_per_tile, n_tiles, shift, plan);
         return check_launch("forward_sign_lds");
     }
@@ -3230,7 +3251,7 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
             const int strips_x = (w + kFwd2Cols - 1) / kFwd2Cols;
             const unsigned n_items = (unsigned)strips_x * row_groups * K;
             const dim3 gr(xcd_grid(n_items)), b(64);
-#define SRX_S2W(CHN, BYTES, YS) hipLaunchKernelGGL((k_forward_sign_s2w<CHN, BYTES>), gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride, raw_bwd, YS, signs, K, g, strips_x, n_items)
+#define SRX_S2W(CHN, BYTES, YS) SRX_LAUNCH_TIMED((k_forward_sign_s2w<CHN, BYTES>), gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride, raw_bwd, YS, signs, K, g, strips_x, n_items)
             if (y_bytes && ch == 1)
                 SRX_S2W(1, true, *y_bytes);
             else if (y_bytes)
@@ -3248,17 +3269,17 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
         if (y_bytes)
         {
             if (ch == 1)
-                hipLaunchKernelGGL((k_forward_sign_s2<1, true>), gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride,
+                SRX_LAUNCH_TIMED((k_forward_sign_s2<1, true>), gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride,
                                    raw_bwd, *y_bytes, signs, K, g, strips_x, n_items);
             else
-                hipLaunchKernelGGL((k_forward_sign_s2<3, true>), gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride,
+                SRX_LAUNCH_TIMED((k_forward_sign_s2<3, true>), gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride,
                                    raw_bwd, *y_bytes, signs, K, g, strips_x, n_items);
         }
         else if (ch == 1)
-            hipLaunchKernelGGL((k_forward_sign_s2<1, false>), gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride,
+            SRX_LAUNCH_TIMED((k_forward_sign_s2<1, false>), gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride,
                                raw_bwd, y, signs, K, g, strips_x, n_items);
         else
-            hipLaunchKernelGGL((k_forward_sign_s2<3, false>), gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride,
+            SRX_LAUNCH_TIMED((k_forward_sign_s2<3, false>), gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride,
                                raw_bwd, y, signs, K, g, strips_x, n_items);
         return check_launch("forward_sign_s2");
     }
@@ -3267,7 +3288,7 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
     {
         const int w = hr_cols / scale, h = hr_rows / scale;
         const dim3 gr((w + kTileLrW - 1) / kTileLrW, (h + kTileLrH - 1) / kTileLrH, K), b(256);
-#define SRX_TILE(CHN, FIVE) hipLaunchKernelGGL((k_forward_sign_tile<CHN, FIVE>), gr, b, tile_lds, st, X, hr_rows, hr_cols, generic_plane_stride, raw_bwd, y, signs, scale, g)
+#define SRX_TILE(CHN, FIVE) SRX_LAUNCH_TIMED((k_forward_sign_tile<CHN, FIVE>), gr, b, tile_lds, st, X, hr_rows, hr_cols, generic_plane_stride, raw_bwd, y, signs, scale, g)
         if (ch == 1 && g.n == 5)
             SRX_TILE(1, true);
         else if (ch == 1)
@@ -3282,10 +3303,10 @@ int launch_forward_sign(const float* X, int hr_rows, int hr_cols, int ch, const 
     const dim3 b(64, 4);
     const dim3 gr = grid2d(hr_cols / scale, hr_rows / scale, b, K);
     if (ch == 1)
-        hipLaunchKernelGGL(k_forward_sign<1>, gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride, raw_bwd, y, signs,
+        SRX_LAUNCH_TIMED(k_forward_sign<1>, gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride, raw_bwd, y, signs,
                            scale, g);
     else
-        hipLaunchKernelGGL(k_forward_sign<3>, gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride, raw_bwd, y, signs,
+        SRX_LAUNCH_TIMED(k_forward_sign<3>, gr, b, 0, st, X, hr_rows, hr_cols, generic_plane_stride, raw_bwd, y, signs,
                            scale, g);
     return check_launch("forward_sign");
 }
@@ -3391,7 +3412,7 @@ int launch_backproject_update(const float* X, float* X_out, int hr_rows, int hr_
                 maps.p[k] = dec_fwd->p[k + 1], sgs.p[k] = signs.p[k + 1];
             Kr = K - 1;
         }
-#define SRX_UPD(CHN, FT) hipLaunchKernelGGL((k_backproject_update_s4<CHN, FT>), gr, b, 0, st, X, X_out, hr_rows, hr_cols, ps, maps, sgs, Kr, fw, ws, tau, lambda, tiles_x, n_tiles, still)
+#define SRX_UPD(CHN, FT) SRX_LAUNCH_TIMED((k_backproject_update_s4<CHN, FT>), gr, b, 0, st, X, X_out, hr_rows, hr_cols, ps, maps, sgs, Kr, fw, ws, tau, lambda, tiles_x, n_tiles, still)
         if (ch == 1 && scale == 4)
             SRX_UPD(1, 2);
         else if (ch == 1)
@@ -3406,10 +3427,10 @@ int launch_backproject_update(const float* X, float* X_out, int hr_rows, int hr_
     const dim3 b(64, 4);
     const dim3 gr = grid2d(hr_cols, hr_rows, b);
     if (ch == 1)
-        hipLaunchKernelGGL(k_backproject_update<1>, gr, b, 0, st, X, X_out, hr_rows, hr_cols, raw_fwd, signs, K, scale,
+        SRX_LAUNCH_TIMED(k_backproject_update<1>, gr, b, 0, st, X, X_out, hr_rows, hr_cols, raw_fwd, signs, K, scale,
                            g, w, tau, lambda);
     else
-        hipLaunchKernelGGL(k_backproject_update<3>, gr, b, 0, st, X, X_out, hr_rows, hr_cols, raw_fwd, signs, K, scale,
+        SRX_LAUNCH_TIMED(k_backproject_update<3>, gr, b, 0, st, X, X_out, hr_rows, hr_cols, raw_fwd, signs, K, scale,
                            g, w, tau, lambda);
     return check_launch("backproject_update");
 }

@@ -277,8 +277,8 @@ int Solver::collect_timing(hipStream_t st)
     for (int it = 0; it < pending_iters_; ++it)
     {
         float a = 0.f, b = 0.f;
-        SRX_HIP(hipEventElapsedTime(&a, events_[3 * it], events_[3 * it + 1]));
-        SRX_HIP(hipEventElapsedTime(&b, events_[3 * it + 1], events_[3 * it + 2]));
+        SRX_HIP(hipEventElapsedTime(&a, events_[4 * it], events_[4 * it + 1]));
+        SRX_HIP(hipEventElapsedTime(&b, events_[4 * it + 2], events_[4 * it + 3]));
         fwd_ms_ += a;
         bwd_ms_ += b;
     }
@@ -411,33 +411,37 @@ int Solver::run(const float* const* y, const float* const* rel, int K, int base_
     {
         if (int rc = collect_timing(st)) // events of the previous run are about to be re-recorded
             return rc;
-        while ((int)events_.size() < 3 * p.iterations)
+        while ((int)events_.size() < 4 * ((p.iterations + kTimingStride - 1) / kTimingStride))
         {
             hipEvent_t e;
             SRX_HIP(hipEventCreate(&e));
             events_.push_back(e);
         }
     }
-    // Events between two launches delay the second one a little, so only every kTimingStride-th
-    // iteration is bracketed; the averages are over those.
+    // Every kTimingStride-th iteration is timed: its two launches carry a start and a stop event each, tied to the
+    // kernels' own begin and end (g_launch_timer); the averages are over those iterations.
     int timed = 0;
+    struct Disarm
+    {
+        ~Disarm() { g_launch_timer = LaunchTimer{}; }
+    } disarm;
     for (int it = 0; it < p.iterations; ++it)
     {
         const bool time_it = timing_ && it % kTimingStride == 0;
         if (time_it)
-            SRX_HIP(hipEventRecord(events_[3 * timed], st));
+            g_launch_timer = LaunchTimer{events_[4 * timed], events_[4 * timed + 1]};
         if (int rc = launch_forward_sign(x_[cur_].as<float>(), (int)R, (int)C, ch, bwd, fastA ? &dbwd : nullptr, ys,
                                          sgm, K, s, gauss_, ps_, st, have_bytes ? &ys8 : nullptr, still, tile_plan))
             return rc;
         if (time_it)
-            SRX_HIP(hipEventRecord(events_[3 * timed + 1], st));
+            g_launch_timer = LaunchTimer{events_[4 * timed + 2], events_[4 * timed + 3]};
         if (int rc = launch_backproject_update(x_[cur_].as<float>(), x_[cur_ ^ 1].as<float>(), (int)R, (int)C, ch,
                                                fwd, fastB ? &dfwd : nullptr, sg, K, s, gauss_, btv_, p.tau, p.lambda,
                                                st, still))
             return rc;
         if (time_it)
         {
-            SRX_HIP(hipEventRecord(events_[3 * timed + 2], st));
+            g_launch_timer = LaunchTimer{};
             ++timed;
         }
         cur_ ^= 1;

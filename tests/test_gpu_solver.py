@@ -365,6 +365,30 @@ def test_batch_process_8u_host(rng, s):
     assert np.array_equal(oracle.btvl1_process(y, fl, 2, p), outf)
 
 
+def test_kernel_timing_times_every_eighth_iteration_and_changes_nothing():
+    """kernelTiming = 1: every eighth iteration's two launches carry events tied to the kernels' begin and end;
+    kernelTimes() adds them up.  The result of the solve is the same with and without."""
+    from superresolution_amd import api, synth
+
+    K, rows, cols, ch = 5, 64, 96, 3
+    lr, flows, _ = synth.make_sequence(K, rows, cols, ch, 4, seed=31)
+    y = [f.numpy().astype(np.float32) for f in lr]
+    fl = [f.numpy() for f in flows]
+    sr = api.BTV_L1()
+    sr.set("iterations", 20)
+    plain = sr.process(y, fl, 2)
+    sr.set("kernelTiming", 1)
+    timed = sr.process(y, fl, 2)
+    assert np.array_equal(plain, timed)
+    f, b, n = sr.kernelTimes()
+    assert n == 3 and 0 < f < 50 and 0 < b < 50  # iterations 0, 8, 16; milliseconds, summed
+    sr.process(y, fl, 2)
+    f2, b2, n2 = sr.kernelTimes()
+    assert n2 == 6 and f2 > f and b2 > b
+    sr.set("kernelTiming", 1)  # setting it again starts the sums afresh
+    assert sr.kernelTimes() == (0.0, 0.0, 0)
+
+
 def test_batch_process_with_flow_plugin(rng):
     """process(src, dst, baseIdx) computes flow frame i -> base through the plug-in (lib/src/btv_l1.cpp:297-326)."""
     from superresolution_amd import api
