@@ -326,7 +326,9 @@ SRX_API int srx_process_device(srx_handle* h, const float* const* y_host, const 
 /* Per-kernel timing of the solver loop, measured with HIP events on the
  * handle's stream while the int parameter "kernelTiming" is 1 (setting it also
  * clears the totals): summed durations of the forward (sign) and
- * back-projection/update launches and the number of iterations they cover.
+ * back-projection/update launches and the number of iterations they cover
+ * (every eighth iteration of a solve is timed, with events tied to the
+ * kernels' own begin and end).
  * Synchronises the stream.  No counterpart in the reference (its samples time
  * whole frames, samples/video/main.cpp:40-47). */
 SRX_API int srx_kernel_times(srx_handle* h, double* forward_ms, double* backproject_ms, long* iterations);
