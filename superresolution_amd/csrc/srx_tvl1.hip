@@ -808,8 +808,13 @@ __device__ __forceinline__ float lane_right(float v)
 // operands as by one launch per iteration.  The launch protocol (which iterations a launch covers, what it does
 // once an earlier iteration has met the threshold) is that of k_tvl1_multi.
 constexpr int kRowsW = 128, kRowsTW = 120, kRowsHX = 4;
+// waves per SIMD the 4-iteration form is compiled for: at 4 (128 registers) it spills 15 registers, at 3 it needs
+// 140 and none; measured 2-3 % faster per pair without the spills
+#ifndef SRX_ROWS_WAVES
+#define SRX_ROWS_WAVES 3
+#endif
 template <int KT, int RPT, int NT>
-__global__ __launch_bounds__(NT, 4) void k_tvl1_rows(Tvl1Planes P, int rows, int cols, float l_t, float theta, float taut,
+__global__ __launch_bounds__(NT, KT >= 4 ? SRX_ROWS_WAVES : 4) void k_tvl1_rows(Tvl1Planes P, int rows, int cols, float l_t, float theta, float taut,
                                                    unsigned long long* __restrict__ err, int n_err, int it0, int n_iter,
                                                    unsigned long long thr, Guard guard)
 {
