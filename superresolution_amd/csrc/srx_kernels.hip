@@ -1241,6 +1241,7 @@ template <int N> struct __attribute__((packed, aligned(4))) packed_floats
 // Which rows a tile holds never changes a value.  One block, a wave per strip; plan[t] = (strip, first row, end
 // row, 0); spare entries and tiles that a single costly row left without rows have first row == end row.
 constexpr int kPlanThreads = 1024, kPlanMaxStrips = 256;
+constexpr int kPlanLdsCosts = 12288; // (LR rows x strips) up to which the costs are kept in LDS
 constexpr int kPlanPerTile = 80; // a tile's start-up in units of PlanCost (five rows served from the window)
 struct PlanCost
 {
@@ -1253,15 +1254,37 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(PtrList grp_bwd, in
     __shared__ int s_total[kPlanMaxStrips], s_first[kPlanMaxStrips + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = H >> 2;
     const size_t flag_at = 3 * ((size_t)H * W / 4) * sizeof(uint32_t);
-    for (int i = tid; i < h * strips_x; i += kPlanThreads)
+    // (four rows' flags per load, the loads of all frames in flight together; the costs stay in LDS where they fit)
+    __shared__ int s_cost[kPlanLdsCosts];
+    const int cells = h * strips_x;
+    if (cells <= kPlanLdsCosts)
+        cost = s_cost;
+    for (int i4 = tid; 4 * i4 < cells; i4 += kPlanThreads)
     {
-        int extra = 0;
-        for (int k = 0; k < K; ++k)
+        int extra[4] = {0, 0, 0, 0};
+        for (int k0 = 0; k0 < K; k0 += 8) // eight frames' loads in flight together
         {
-            const uint8_t flag = ((const uint8_t*)grp_bwd.p[k] + flag_at)[i];
-            extra += (flag & kRowKindMask) == kRowOutside ? pc.outside : ((flag & kRowLeaves) ? pc.mixed : 0);
+            uint32_t f4[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+            {
+                f4[u] = 0; // (flag_at is a multiple of 4; a word's last bytes may belong to nothing: never used)
+                if (k0 + u < K)
+                    f4[u] = ((const uint32_t*)((const uint8_t*)grp_bwd.p[k0 + u] + flag_at))[i4];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                {
+                    const uint32_t flag = (f4[u] >> (8 * b)) & 0xFFu; // 0 (a mixed row that stays inside) beyond K
+                    extra[b] += (flag & kRowKindMask) == kRowOutside ? pc.outside : ((flag & kRowLeaves) ? pc.mixed : 0);
+                }
         }
-        cost[i] = pc.inside + min(extra, pc.most_extra);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if (4 * i4 + b < cells)
+                cost[4 * i4 + b] = pc.inside + min(extra[b], pc.most_extra);
     }
     for (int t = tid; t < n_tiles; t += kPlanThreads)
         plan[t] = make_int4(0, 0, 0, 0);
@@ -1282,33 +1305,53 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(PtrList grp_bwd, in
     }
     __syncthreads();
     // the smallest cost per tile L (start-up included) at which the strips need no more than n_tiles tiles:
-    // tiles(s, L) = ceil(total_s / (L - kPlanPerTile)), at least 1 and at most h / min_rows; every thread runs the
-    // same search
+    // tiles(s, L) = ceil(total_s / (L - kPlanPerTile)), at least 1 and at most h / min_rows.  One wave searches,
+    // its lanes taking the strips in turn (every thread on its own would spend the kernel's time on the divisions).
     const int most = max(1, h / max(pc.min_rows, 1));
-    int lo = kPlanPerTile + 1, hi = kPlanPerTile + 1;
-    for (int sidx = 0; sidx < strips_x; ++sidx)
-        hi = max(hi, kPlanPerTile + s_total[sidx]);
-    while (lo < hi)
+    if (wave == 0)
     {
-        const int mid = lo + (hi - lo) / 2;
-        int need = 0;
-        for (int sidx = 0; sidx < strips_x; ++sidx)
-            need += min(most, max(1, (s_total[sidx] + (mid - kPlanPerTile) - 1) / (mid - kPlanPerTile)));
-        if (need <= n_tiles)
-            hi = mid;
-        else
-            lo = mid + 1;
-    }
-    const int share = lo - kPlanPerTile;
-    if (tid == 0)
-    {
-        int at = 0;
-        for (int sidx = 0; sidx < strips_x; ++sidx)
+        int top = 0;
+        for (int sidx = lane; sidx < strips_x; sidx += 64)
+            top = max(top, s_total[sidx]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            top = max(top, __shfl_xor(top, o, 64));
+        int lo = kPlanPerTile + 1, hi = kPlanPerTile + max(top, 1);
+        while (lo < hi) // lo, hi and mid are the same in every lane
         {
-            s_first[sidx] = at;
-            at += min(most, max(1, (s_total[sidx] + share - 1) / share));
+            const int mid = lo + (hi - lo) / 2;
+            int need = 0;
+            for (int sidx = lane; sidx < strips_x; sidx += 64)
+                need += min(most, max(1, (s_total[sidx] + (mid - kPlanPerTile) - 1) / (mid - kPlanPerTile)));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+                need += __shfl_xor(need, o, 64);
+            if (need <= n_tiles)
+                hi = mid;
+            else
+                lo = mid + 1;
         }
-        s_first[strips_x] = at; // <= n_tiles
+        const int share = lo - kPlanPerTile;
+        // first tile of every strip: a running sum over the strips, 64 at a time
+        int base = 0;
+        for (int s0 = 0; s0 < strips_x; s0 += 64)
+        {
+            const int sidx = s0 + lane;
+            const int mine = sidx < strips_x ? min(most, max(1, (s_total[sidx] + share - 1) / share)) : 0;
+            int incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1)
+            {
+                const int v = __shfl_up(incl, o, 64);
+                if (lane >= o)
+                    incl += v;
+            }
+            if (sidx < strips_x)
+                s_first[sidx] = base + incl - mine;
+            base += __shfl(incl, 63, 64);
+        }
+        if (lane == 0)
+            s_first[strips_x] = base; // <= n_tiles
     }
     __syncthreads();
     int* const fields = (int*)plan;
@@ -1336,17 +1379,18 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(PtrList grp_bwd, in
                 before += v;
         }
         long long acc = before - part;
-        // tile j of the strip starts behind the first row at which the running cost reaches j shares
+        // tile j of the strip starts behind the first row at which the running cost reaches j shares, i.e.
+        // acc * T >= j * total (one division per lane for the shares reached in front of its rows, products after)
+        int j = (int)(acc * T / total);
         for (int y = ya; y < yb; ++y)
         {
-            const long long next = acc + cost[y * strips_x + sidx];
-            const int j0 = (int)(acc * T / total), j1 = (int)min((long long)T - 1, next * T / total);
-            for (int j = j0 + 1; j <= j1; ++j)
+            acc += cost[y * strips_x + sidx];
+            while (j + 1 < T && (long long)(j + 1) * total <= acc * T)
             {
+                ++j;
                 fields[4 * (first + j) + 1] = y + 1;
                 fields[4 * (first + j - 1) + 2] = y + 1;
             }
-            acc = next;
         }
     }
 }
@@ -3179,7 +3223,7 @@ int launch_plan_forward_tiles(const PtrList& dec_bwd, int K, int hr_rows, int hr
                               bool* planned, hipStream_t st)
 {
     *planned = false;
-    const int w = hr_cols / 4, h = hr_rows / 4;
+    const int w = hr_cols / 4;
     const int strips_x = (w + kFwdStrip - 1) / kFwdStrip;
     const int cus = forward_device_setup();
     if (cus == 0)
