@@ -752,6 +752,91 @@ __global__ void k_resize_cubic(const float* __restrict__ src, int srows, int sco
         dst[ps ? c * ps + o : o * CH + c] = v[c];
 }
 
+// The same enlargement by 4 into planes, a thread per LR cell (the 4 x 4 HR pixels of rows 4y .. 4y+3 and columns
+// 4x .. 4x+3): their taps come from 5 x 5 LR pixels, the row passes are shared by the pixels of a column - exactly
+// the sums cubic_sample forms, in its order - and every plane's four pixels of a row leave as one 16-byte store.
+// Per cell the four columns' first taps are (s, s, s + o, s + o) with o = 0 or 1, the four rows' likewise
+// (cubic_table_x / _y at scale 4); a cell whose tables say otherwise takes the per-pixel routine.
+template <int CH>
+__global__ __launch_bounds__(256) void k_resize_cubic_cells(const float* __restrict__ src, int srows, int scols,
+                                                            CubicTables t, float* __restrict__ dst, size_t ps)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= scols || y >= srows)
+        return;
+    const int dcols = 4 * scols;
+    int sy[4], sxv[4];
+    float4 al[4], be[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+    {
+        sy[r] = t.yofs[4 * y + r], be[r] = t.beta[4 * y + r];
+        sxv[r] = t.xofs[4 * x + r], al[r] = t.alpha[4 * x + r];
+    }
+    const int rb = sy[0], sb = sxv[0];
+    const bool down = sy[2] != rb, shifted = sxv[2] != sb;
+    const bool shared_taps = sy[1] == rb && sy[3] == sy[2] && (sy[2] == rb || sy[2] == rb + 1) && sxv[1] == sb &&
+                             sxv[3] == sxv[2] && (sxv[2] == sb || sxv[2] == sb + 1);
+    float out[4][4][CH]; // [HR row][column][channel]
+    if (shared_taps)
+    {
+        float hv[5][4][CH];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+        {
+            const float* S = src + (size_t)clampi(rb - 1 + i, 0, srows - 1) * scols * CH;
+            int col[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                col[k] = clampi(sb - 1 + k, 0, scols - 1) * CH;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+            {
+                float a[5], b[4];
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    a[k] = S[col[k] + c];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    b[k] = shifted ? a[k + 1] : a[k];
+                hv[i][0][c] = a[0] * al[0].x + a[1] * al[0].y + a[2] * al[0].z + a[3] * al[0].w;
+                hv[i][1][c] = a[0] * al[1].x + a[1] * al[1].y + a[2] * al[1].z + a[3] * al[1].w;
+                hv[i][2][c] = b[0] * al[2].x + b[1] * al[2].y + b[2] * al[2].z + b[3] * al[2].w;
+                hv[i][3][c] = b[0] * al[3].x + b[1] * al[3].y + b[2] * al[3].z + b[3] * al[3].w;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+        {
+            const bool dn = r >= 2 && down; // rows 0, 1 start at rb, rows 2, 3 at rb or rb + 1
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                {
+                    const float v0 = dn ? hv[1][q][c] : hv[0][q][c], v1 = dn ? hv[2][q][c] : hv[1][q][c];
+                    const float v2 = dn ? hv[3][q][c] : hv[2][q][c], v3 = dn ? hv[4][q][c] : hv[3][q][c];
+                    out[r][q][c] = v0 * be[r].x + v1 * be[r].y + v2 * be[r].z + v3 * be[r].w;
+                }
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                cubic_sample<CH>(src, srows, scols, sxv[q], al[q], sy[r], be[r], out[r][q]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            *(float4*)(dst + c * ps + (size_t)(4 * y + r) * dcols + 4 * x) =
+                make_float4(out[r][0][c], out[r][1][c], out[r][2][c], out[r][3][c]);
+}
+
 // interleaved <-> planar copies (stage-level entry points and x_full output)
 template <int CH>
 __global__ void k_relayout(const float* __restrict__ src, float* __restrict__ dst, size_t count, size_t ps,
@@ -3056,6 +3141,16 @@ int launch_resize_cubic(const float* src, int srows, int scols, int ch, const Cu
                         int dcols, size_t plane_stride, hipStream_t st)
 {
     const dim3 b(64, 4);
+    if (plane_stride != 0 && plane_stride % 4 == 0 && drows == 4 * srows && dcols == 4 * scols && (ch == 1 || ch == 3) &&
+        g_kernel_path == 0)
+    {
+        const dim3 gc = grid2d(scols, srows, b);
+        if (ch == 1)
+            hipLaunchKernelGGL(k_resize_cubic_cells<1>, gc, b, 0, st, src, srows, scols, t, dst, plane_stride);
+        else
+            hipLaunchKernelGGL(k_resize_cubic_cells<3>, gc, b, 0, st, src, srows, scols, t, dst, plane_stride);
+        return check_launch("resize_cubic_cells");
+    }
     const dim3 g = grid2d(dcols, drows, b);
     switch (ch)
     {
