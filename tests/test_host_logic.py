@@ -284,4 +284,13 @@ def test_dry_handle_walks_process_and_rejects_compute_calls():
     assert len(calls) == 2
     with pytest.raises(L.SrxError):
         sr.calcFlow(frames[0], frames[1])
+    # pairs side by side need a GPU handle too; the number in flight is a checked parameter of the handle
+    import ctypes as C
+    with pytest.raises(L.SrxError, match="GPU handle"):
+        L.check(L.lib().srx_flow_calc_device_pairs(sr.handle, 0, None, None, 6, 8, None, None, 2))
+    assert sr.getInt("flowPairsInFlight") == 3
+    sr.set("flowPairsInFlight", 1)
+    with pytest.raises(L.SrxError, match="flowPairsInFlight"):
+        sr.set("flowPairsInFlight", 0)
+    assert sr.getInt("flowPairsInFlight") == 1
     assert L.lib().srx_get_kernel_path() == 0
